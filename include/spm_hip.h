@@ -1,0 +1,161 @@
+/*
+ * spm_hip.h -- C ABI of the MI355X-native online pattern-matching engine (libspm_hip.so).
+ *
+ * This is the drop-in boundary for libspm's matcher hot path.  The reference has no FFI for this path:
+ * its boundary is the header-only C++ template API
+ *     spm::{horspool,shiftor,myers,restorable_*}_matcher::operator()(haystack, callback)
+ *         /root/reference/libspm/libspm/matcher/seqan_pattern_base.hpp:40-52
+ * so the entry points below are what a binding for that call operator needs: build the pattern tables once
+ * (the matcher constructors), hand over a haystack of 1-byte ranks, run one scan, read back the hits in the
+ * order the callback would have seen them.  include/libspm/ holds the C++ mirror of the reference API that
+ * marshals to these calls; INTEGRATION.md shows the binding from the reference side.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function returns 0 on success and a
+ * negative spm_status on failure; spm_hip_last_error() gives the message.  Nothing throws across the ABI.
+ * Handles are opaque and owned by the library.  Not thread-safe per context; contexts are independent.
+ */
+#ifndef SPM_HIP_H
+#define SPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spm_ctx spm_ctx;           /* one device + one HIP stream */
+typedef struct spm_text spm_text;         /* haystack resident in HBM, one uint8 rank per symbol */
+typedef struct spm_patterns spm_patterns; /* compiled needle set: Peq / mask tables, seed index */
+typedef struct spm_hits spm_hits;         /* result of one scan */
+
+enum spm_status {
+    SPM_OK = 0,
+    SPM_E_INVALID = -1,     /* bad argument */
+    SPM_E_HIP = -2,         /* HIP runtime error (message has the hipError string) */
+    SPM_E_NOMEM = -3,
+    SPM_E_UNSUPPORTED = -4, /* e.g. needle longer than SPM_MAX_NEEDLE */
+    SPM_E_OVERFLOW = -5     /* hit buffer too small; see spm_scan_opts.max_hits */
+};
+
+/* Which reference matcher a pattern set stands for. */
+enum spm_algo {
+    SPM_ALGO_SHIFTOR = 0,      /* spm::shiftor_matcher   matcher/shiftor_matcher.hpp:20-41  -> begin positions */
+    SPM_ALGO_MYERS = 1,        /* spm::myers_matcher     matcher/myers_matcher.hpp:19-54    -> (end, distance) */
+    SPM_ALGO_MYERS_PREFIX = 2, /* spm::restorable_myers_prefix_matcher  matcher/myers_prefix_matcher_restorable.hpp:117-160 */
+    SPM_ALGO_HORSPOOL = 3      /* spm::horspool_matcher  matcher/horspool_matcher.hpp:20-41 -> begin positions
+                                  (same hit set as Shift-Or: every occurrence) */
+};
+
+enum spm_engine {
+    SPM_ENGINE_AUTO = 0,  /* seed filter when the pattern set admits one, else brute force */
+    SPM_ENGINE_BRUTE = 1, /* one lane per pattern, every text symbol through the recurrence */
+    SPM_ENGINE_FILTER = 2 /* lossless pigeonhole seed filter + bit-vector verification */
+};
+
+#define SPM_MAX_NEEDLE 2048u
+
+/* One hit record, 16 bytes.  Replaces what the reference's callback reads off the seqan2::Finder:
+ *   Myers:  pos = seqan2::endPosition(finder)   (exclusive end; test/api/libspm/matcher/myers_matcher_test.cpp:49-51)
+ *           score = edit distance of that end position (the pattern state's `errors`)
+ *   exact:  pos = seqan2::beginPosition(finder) (test/api/libspm/matcher/horspool_matcher_test.cpp:48-50), score = 0
+ * `pattern` = index into the pattern set.  Positions are relative to text[0] plus spm_scan_opts.pos_offset. */
+typedef struct spm_hit {
+    uint64_t pos;
+    uint32_t pattern;
+    int32_t score;
+} spm_hit;
+
+typedef struct spm_scan_opts {
+    uint32_t engine;       /* spm_engine */
+    uint32_t left_context; /* 0: text[begin] is the first symbol of the haystack (cold start, the reference's
+                              operator() semantics).  1: the symbols before `begin` belong to the same haystack
+                              and may be read as warm-up, so the hits equal those of a scan of the whole text
+                              whose last symbol lies in [begin,end) -- the shard rule of SURVEY.md 8(e). */
+    uint64_t pos_offset;   /* added to every reported position (global coordinate of text[0]) */
+    uint64_t max_hits;     /* capacity of the hit buffer; 0 = library default */
+    uint32_t sort;         /* 1: hits are returned sorted by (pattern, pos) -- callback order per matcher */
+    uint32_t reserved;
+} spm_scan_opts;
+
+/* Per-scan device timings, HIP events on the context's stream (ms). */
+typedef struct spm_scan_stats {
+    float ms_total;
+    float ms_main;        /* the dominant kernel: brute-force scan, or the seed filter */
+    float ms_verify;      /* filter engine: bit-vector verification of the candidates */
+    uint32_t engine_used; /* spm_engine actually run */
+    uint32_t fell_back;   /* 1 if the filter engine overflowed and the brute engine re-ran the scan */
+    uint64_t n_candidates;
+    uint64_t n_hits;
+    uint32_t main_launches;
+    uint32_t reserved;
+} spm_scan_stats;
+
+/* ---- context -------------------------------------------------------------------------------------- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create a private one. */
+int spm_hip_init(int device, void *stream, spm_ctx **out);
+void spm_hip_destroy(spm_ctx *ctx);
+const char *spm_hip_last_error(const spm_ctx *ctx); /* ctx may be NULL: error of the failed spm_hip_init */
+int spm_hip_synchronize(spm_ctx *ctx);
+
+/* ---- haystack: replaces spm::make_seqan_container(views::all(haystack)), seqan_pattern_base.hpp:44-45 ----
+ * sigma = alphabet size (4 dna4, 5 dna5, 15 dna15; seqan/alphabet.hpp:100-105); symbols are ranks < sigma. */
+int spm_hip_text_upload(spm_ctx *ctx, const uint8_t *ranks, uint64_t n, uint32_t sigma, spm_text **out);
+/* Borrow a device buffer (16-byte aligned) that the caller keeps alive, e.g. a torch uint8 tensor. */
+int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_t n, uint32_t sigma, spm_text **out);
+/* Synthetic uniform dna4 text generated in HBM: base(i) of SURVEY.md 8(d) for i in [global_begin, +n). */
+int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, spm_text **out);
+int spm_hip_text_download(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t n, uint8_t *out);
+uint64_t spm_hip_text_length(const spm_text *text);
+const void *spm_hip_text_device_ptr(const spm_text *text);
+void spm_hip_text_destroy(spm_text *text);
+
+/* ---- needles: replaces the matcher constructors (myers_matcher.hpp:40-43, shiftor_matcher.hpp:38-40,
+ * horspool_matcher.hpp:38-40, myers_matcher_restorable.hpp:132).  ranks_concat holds the needles back to back,
+ * needle p = ranks_concat[offsets[p] .. offsets[p+1]).  k[p] = max_error_count of needle p (NULL = all 0;
+ * ignored by the exact matchers). */
+int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ranks_concat, const uint32_t *offsets,
+                            uint32_t n_patterns, const uint16_t *k, uint32_t sigma, spm_patterns **out);
+void spm_hip_patterns_destroy(spm_patterns *p);
+/* spm::window_size (seqan_pattern_base.hpp:97-99, myers_matcher.hpp:51-53): |P| exact, |P|+k Myers, 0 if empty. */
+uint64_t spm_hip_patterns_window_size(const spm_patterns *p, uint32_t pattern);
+/* 1 if the set admits the lossless seed filter (dna4, every needle long enough for its k). */
+int spm_hip_patterns_filterable(const spm_patterns *p);
+
+/* ---- matcher state: replaces capture()/restore() (myers_matcher_restorable.hpp:57-63,136-142;
+ * shiftor_matcher_restorable.hpp:44-50).  A state blob holds one record per pattern, each
+ * spm_hip_patterns_state_stride() bytes:
+ *   Myers:    int32 score; uint32 n_words; uint64 vp[n_words]; uint64 vn[n_words]     (n_words = ceil(|P|/64))
+ *   Shift-Or: uint32 n_words; uint32 pad;  uint32 r[n_words]                          (n_words = ceil(|P|/32))
+ * spm_hip_patterns_state_init writes the constructor-time state (VP=~0, VN=0, score=|P|; R=~0). */
+size_t spm_hip_patterns_state_stride(const spm_patterns *p);
+int spm_hip_patterns_state_init(const spm_patterns *p, void *state);
+
+/* ---- scan: replaces seqan_pattern_base::operator()(haystack, callback), seqan_pattern_base.hpp:40-52 ----
+ * Scans text[begin,end).  state_in == NULL: fresh matcher (non-restorable semantics).  state_in != NULL:
+ * continue from that state (restorable semantics, myers_matcher_restorable.hpp:72-82); state_out (may alias
+ * state_in, may be NULL) receives the state after the last symbol. */
+int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
+                 const spm_scan_opts *opts, const void *state_in, void *state_out, spm_hits **out);
+
+/* ---- hits ------------------------------------------------------------------------------------------ */
+/* Host view, sorted by (pattern, pos): per pattern this is the order the reference's callback fires in. */
+int spm_hip_hits_view(spm_hits *hits, const spm_hit **records, uint64_t *n);
+/* Device view (unsorted unless opts.sort): pointer to n spm_hit records in HBM, for an RCCL gatherv. */
+int spm_hip_hits_device(spm_hits *hits, const void **device_records, uint64_t *n);
+int spm_hip_hits_stats(const spm_hits *hits, spm_scan_stats *out);
+/* order-independent checksum: sum over hits of mix64(pos ^ pattern<<40 ^ score<<58), SURVEY.md 8(d) */
+uint64_t spm_hip_hits_checksum(spm_hits *hits);
+void spm_hip_hits_destroy(spm_hits *hits);
+
+/* ---- synthetic needles of the benchmark configs (host side) -------------------------- */
+uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
+                               uint32_t kmax, uint8_t *out);
+uint64_t spm_hip_mix64(uint64_t z);
+
+const char *spm_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPM_HIP_H */

@@ -1,0 +1,10 @@
+"""libspm_amd -- MI355X-native online pattern matching behind libspm's matcher API.
+
+Only what the hot path needs lives here: csrc/ (HIP kernels + the C ABI of include/spm_hip.h), the ctypes binding
+(capi), a thin object layer (engine) and the multi-GPU hit gather (dist).  The C++ mirror of the reference's
+header-only API is in include/libspm/.
+"""
+from . import capi  # noqa: F401
+from .capi import (ALGO_HORSPOOL, ALGO_MYERS, ALGO_MYERS_PREFIX, ALGO_SHIFTOR, ENGINE_AUTO, ENGINE_BRUTE,  # noqa: F401
+                   ENGINE_FILTER, SpmError)
+from .engine import HIT_DTYPE, Context, Hits, PatternSet, Text, scan, synth_pattern  # noqa: F401

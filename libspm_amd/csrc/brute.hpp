@@ -1,0 +1,336 @@
+// brute.hpp -- brute-force scan kernels: ONE LANE PER PATTERN, every text symbol through the recurrence.
+//
+// This is the kernel shape BASELINE.json's north_star names: the 64 lanes of a wavefront hold 64 different
+// needles; the text symbol is wave-uniform; the per-needle match bit-masks (Peq) sit in LDS laid out
+// [symbol][word][lane] so that a wave reads one conflict-free 256-byte row per word; the text is streamed with
+// coalesced dword loads and broadcast through v_readlane; hits are compacted with ballot/popc.
+//
+// Recurrence (replaces [upstream] _findMyersSmallPatterns/_findMyersLargePatterns, reached from
+// /root/reference/libspm/libspm/matcher/seqan_pattern_base.hpp:60-65 and myers_matcher_restorable.hpp:50-54):
+//   X = Peq[c] | VN;  D0 = ((VP + (X & VP)) ^ VP) | X;  HN = VP & D0;  HP = VN | ~(VP | D0)
+//   X = HP << 1;  VN = X & D0;  VP = (HN << 1) | ~(X | D0);  score += HP[top] - HN[top]
+// on NW 32-bit words with the add carry and the two shift carries chained across words.
+//
+// Layout trick: every needle is TOP-ALIGNED in its NW*32-bit vector (row j of the needle sits at bit off+j,
+// off = 32*NW - |P|).  Bits below `off` are wildcard rows (Peq = 1 for every symbol, VP = 0 initially); they hold
+// D = 0 in every column, exactly like the DP's row 0, so the needle's rows see the same boundary as in the
+// unshifted formulation -- and the score delta is always bit 31 of the top word for every lane, whatever |P|.
+//
+// Tiling (SURVEY.md 8(e) / spm::window_size): the scan range is cut into tiles; a tile starts its recurrence cold
+// W-1 symbols early (W = max |P|+k) and reports only hits whose last symbol it owns.  A cold start at s' computes
+// the DP of the suffix text[s'..]; every cell with D <= k has an optimal alignment that spans <= |P|+k symbols, so
+// value and <= k membership agree with the sequential scan for every owned position.
+#pragma once
+
+#include "common.hpp"
+
+namespace spm_hip
+{
+
+struct brute_params
+{
+    const uint8_t *text;   // text[0] = first symbol; 4-byte aligned
+    uint64_t text_alloc;   // readable bytes from text
+    uint64_t scan_begin;   // owned range: hits whose LAST symbol index is in [scan_begin, scan_end)
+    uint64_t scan_end;
+    uint64_t ctx_begin;    // lowest symbol index that may be consumed as warm-up
+    uint64_t pos_offset;   // added to reported positions
+    uint32_t tile;         // owned symbols per tile (multiple of 4)
+    uint32_t n_tiles;
+    uint32_t n_groups;     // ceil(n_patterns / 64)
+    uint32_t warm;         // warm-up symbols = max window - 1
+    uint32_t sigma;        // rows 0..sigma-1 real symbols, row sigma = "no match" (invalid symbol)
+    uint32_t has_state;    // 1: tile 0 continues from state_in instead of a cold start
+    const uint32_t *peq;   // [group][sigma+1][NW][64]
+    const uint32_t *hp0;   // prefix mode: [group][NW][64] carry-in mask (bit `off`), else nullptr
+    const int32_t *m;      // [group*64] needle lengths (0 = padding lane)
+    const int32_t *k;      // [group*64]
+    const uint32_t *state_in; // [group][2*NW+1][64] internal layout (VP words, VN words, score) or nullptr
+    uint32_t *state_out;      // same layout, or nullptr
+    spm_hit *hits;
+    unsigned long long *counters; // [0] = hit count
+    uint64_t hit_cap;
+};
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// append the hits of one wave: ballot + popc prefix, one atomic per wave
+__device__ __forceinline__ void wave_append_hits(bool is_hit, uint64_t pos, uint32_t pattern, int32_t score,
+                                                 spm_hit *hits, unsigned long long *counter, uint64_t cap)
+{
+    const uint64_t mask = __ballot(is_hit);
+    if (mask == 0)
+        return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = __popcll(mask);
+    unsigned long long base = 0;
+    if (lane == (uint32_t)__ffsll((unsigned long long)mask) - 1)
+        base = atomicAdd(counter, (unsigned long long)n);
+    base = __shfl(base, __ffsll((unsigned long long)mask) - 1);
+    if (is_hit) {
+        const uint64_t idx = base + __popcll(mask & ((1ull << lane) - 1));
+        if (idx < cap) {
+            spm_hit h;
+            h.pos = pos;
+            h.pattern = pattern;
+            h.score = score;
+            hits[idx] = h;
+        }
+    }
+}
+
+// Load the dword holding text[idx..idx+4) for idx % 4 == 0, never touching bytes >= alloc.
+__device__ __forceinline__ uint32_t load_text_dword(const uint8_t *text, uint64_t idx, uint64_t alloc)
+{
+    if (idx + 4 <= alloc)
+        return *reinterpret_cast<const uint32_t *>(text + idx);
+    uint32_t v = 0;
+    for (int b = 0; b < 4; ++b)
+        if (idx + b < alloc)
+            v |= (uint32_t)text[idx + b] << (8 * b);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Myers, NW 32-bit words per needle, one lane per needle.  PREFIX = MyersUkkonenGlobal carry-in.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, bool PREFIX>
+__global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t rows = P.sigma + 1;
+    uint32_t *my_peq = lds + (size_t)wave_in_wg * rows * NW * 64; // this wave's table: [row][word][lane]
+
+    const uint64_t n_items = (uint64_t)P.n_tiles * P.n_groups;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+
+    uint32_t loaded_group = 0xFFFFFFFFu;
+    int32_t my_m = 0, my_k = -1;
+    uint32_t hp0[PREFIX ? NW : 1];
+
+    for (uint64_t item = wave_id; item < n_items; item += n_waves) {
+        const uint32_t group = (uint32_t)(item % P.n_groups);
+        const uint32_t tile = (uint32_t)(item / P.n_groups);
+        if (group != loaded_group) {
+            const uint32_t *src = P.peq + (size_t)group * rows * NW * 64;
+            for (uint32_t i = lane; i < rows * NW * 64; i += 64)
+                my_peq[i] = src[i];
+            my_m = P.m[group * 64 + lane];
+            my_k = my_m > 0 ? P.k[group * 64 + lane] : -1;
+            if (PREFIX) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    hp0[w] = P.hp0[((size_t)group * NW + w) * 64 + lane];
+            }
+            loaded_group = group;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- tile geometry (all wave-uniform) ----
+        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_hi = own_lo + P.tile;
+        if (own_hi > P.scan_end)
+            own_hi = P.scan_end;
+        uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        const bool resume = P.has_state && tile == 0;
+        if (resume)
+            scan_lo = own_lo;
+
+        // ---- initial state ----
+        uint32_t VP[NW], VN[NW];
+        int32_t score;
+        if (resume) {
+            const uint32_t *st = P.state_in + (size_t)group * (2 * NW + 1) * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                VP[w] = st[w * 64];
+                VN[w] = st[(NW + w) * 64];
+            }
+            score = (int32_t)st[2 * NW * 64];
+        } else {
+            const int32_t off = NW * 32 - my_m;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int32_t lo = off - w * 32; // bits >= lo are needle rows
+                VP[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+                VN[w] = 0;
+            }
+            score = my_m;
+        }
+
+        const uint64_t a0 = scan_lo & ~3ull;
+        for (uint64_t cbase = a0; cbase < own_hi; cbase += 256) {
+            const uint64_t my_idx = cbase + (uint64_t)lane * 4;
+            uint32_t v = 0;
+            if (my_idx < own_hi)
+                v = load_text_dword(P.text, my_idx, P.text_alloc);
+            const uint64_t rem = own_hi - cbase;
+            const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
+            const bool interior = (cbase >= scan_lo) && (rem >= 256);
+            for (uint32_t j = 0; j < n_dw; ++j) {
+                const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint64_t p = cbase + (uint64_t)j * 4 + s;
+                    if (!interior && (p < scan_lo || p >= own_hi))
+                        continue;
+                    uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                    c = c < P.sigma ? c : P.sigma;
+                    const uint32_t *row = my_peq + (size_t)c * NW * 64 + lane;
+                    uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t eq = row[w * 64];
+                        const uint32_t X = eq | VN[w];
+                        const uint32_t t = X & VP[w];
+                        uint32_t cout;
+                        const uint32_t sum = __builtin_addc(VP[w], t, carry, &cout);
+                        carry = cout;
+                        const uint32_t D0 = (sum ^ VP[w]) | X;
+                        const uint32_t HN = VP[w] & D0;
+                        const uint32_t HP = VN[w] | ~(VP[w] | D0);
+                        uint32_t Xs = alignbit(HP, hp_prev, 31);
+                        if (PREFIX)
+                            Xs |= hp0[w];
+                        const uint32_t Ts = alignbit(HN, hn_prev, 31);
+                        hp_prev = HP;
+                        hn_prev = HN;
+                        VN[w] = Xs & D0;
+                        VP[w] = Ts | ~(Xs | D0);
+                    }
+                    score += (int32_t)(hp_prev >> 31) - (int32_t)(hn_prev >> 31);
+                    const bool hit = score <= my_k;
+                    if (__ballot(hit) != 0 && p >= own_lo) {
+                        wave_append_hits(hit, p + 1 + P.pos_offset, group * 64 + lane, score, P.hits,
+                                         P.counters, P.hit_cap);
+                    }
+                }
+            }
+        }
+        // The state after the last symbol is exact only when the recurrence ran over every symbol since the
+        // matcher was constructed -- the single-tile resume case (restorable matcher on a chunk).
+        if (P.state_out && tile == P.n_tiles - 1 && P.n_tiles == 1) {
+            uint32_t *st = P.state_out + (size_t)group * (2 * NW + 1) * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                st[w * 64] = VP[w];
+                st[(NW + w) * 64] = VN[w];
+            }
+            st[2 * NW * 64] = (uint32_t)score;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Shift-Or, NW 32-bit words per needle, one lane per needle
+// (replaces [upstream] _findShiftOrSmallNeedle/_findShiftOrLargeNeedle, shiftor_matcher_restorable.hpp:38-41).
+//   R = (R << 1) | mask[c];  occurrence ends here iff bit |P|-1 of R is 0.
+// Same top-aligned layout: wildcard bits below `off` have mask = 0 and R = 0, so bit off-1 always shifts a 0
+// ("empty prefix matches") into the needle's row 0.  Reports begin = end - |P| + 1.
+// state layout: [group][NW][64].
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t rows = P.sigma + 1;
+    uint32_t *my_mask = lds + (size_t)wave_in_wg * rows * NW * 64;
+
+    const uint64_t n_items = (uint64_t)P.n_tiles * P.n_groups;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+
+    uint32_t loaded_group = 0xFFFFFFFFu;
+    int32_t my_m = 0;
+
+    for (uint64_t item = wave_id; item < n_items; item += n_waves) {
+        const uint32_t group = (uint32_t)(item % P.n_groups);
+        const uint32_t tile = (uint32_t)(item / P.n_groups);
+        if (group != loaded_group) {
+            const uint32_t *src = P.peq + (size_t)group * rows * NW * 64;
+            for (uint32_t i = lane; i < rows * NW * 64; i += 64)
+                my_mask[i] = src[i];
+            my_m = P.m[group * 64 + lane];
+            loaded_group = group;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_hi = own_lo + P.tile;
+        if (own_hi > P.scan_end)
+            own_hi = P.scan_end;
+        uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        const bool resume = P.has_state && tile == 0;
+        if (resume)
+            scan_lo = own_lo;
+
+        uint32_t R[NW];
+        if (resume) {
+            const uint32_t *st = P.state_in + (size_t)group * NW * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                R[w] = st[w * 64];
+        } else {
+            const int32_t off = NW * 32 - my_m;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int32_t lo = off - w * 32;
+                R[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+            }
+        }
+        const bool active_lane = my_m > 0;
+
+        const uint64_t a0 = scan_lo & ~3ull;
+        for (uint64_t cbase = a0; cbase < own_hi; cbase += 256) {
+            const uint64_t my_idx = cbase + (uint64_t)lane * 4;
+            uint32_t v = 0;
+            if (my_idx < own_hi)
+                v = load_text_dword(P.text, my_idx, P.text_alloc);
+            const uint64_t rem = own_hi - cbase;
+            const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
+            const bool interior = (cbase >= scan_lo) && (rem >= 256);
+            for (uint32_t j = 0; j < n_dw; ++j) {
+                const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint64_t p = cbase + (uint64_t)j * 4 + s;
+                    if (!interior && (p < scan_lo || p >= own_hi))
+                        continue;
+                    uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                    c = c < P.sigma ? c : P.sigma;
+                    const uint32_t *row = my_mask + (size_t)c * NW * 64 + lane;
+                    uint32_t prev = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t cur = R[w];
+                        R[w] = alignbit(cur, prev, 31) | row[w * 64];
+                        prev = cur;
+                    }
+                    const bool hit = active_lane && ((int32_t)R[NW - 1] >= 0); // bit 31 clear
+                    if (__ballot(hit) != 0 && p >= own_lo) {
+                        // an occurrence that starts before the haystack's first symbol cannot exist; with a
+                        // restored state it can start in an earlier chunk, whose coordinates the caller owns
+                        wave_append_hits(hit, p + 1 - (uint64_t)my_m + P.pos_offset, group * 64 + lane, 0,
+                                         P.hits, P.counters, P.hit_cap);
+                    }
+                }
+            }
+        }
+        if (P.state_out && P.n_tiles == 1) {
+            uint32_t *st = P.state_out + (size_t)group * NW * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                st[w * 64] = R[w];
+        }
+    }
+}
+
+} // namespace spm_hip

@@ -1,0 +1,83 @@
+// common.hpp -- internal types of libspm_hip.so (MI355X / gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/spm_hip.h"
+
+namespace spm_hip
+{
+
+constexpr int kWave = 64; // CDNA wavefront
+
+struct error_sink
+{
+    std::string msg;
+};
+
+extern thread_local std::string g_init_error;
+
+} // namespace spm_hip
+
+struct spm_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    std::string err;
+    // scratch reused across scans
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct spm_text
+{
+    spm_ctx *ctx = nullptr;
+    uint8_t *d = nullptr;
+    uint64_t n = 0;
+    uint64_t alloc = 0; // bytes readable from d (>= n)
+    uint32_t sigma = 4;
+    bool owned = false;
+};
+
+struct spm_hits
+{
+    spm_ctx *ctx = nullptr;
+    spm_hit *d_hits = nullptr;
+    unsigned long long *d_count = nullptr; // [0] hits, [1] candidates, [2] overflow flags
+    uint64_t cap = 0;
+    uint64_t cand_cap = 0;
+    uint64_t n = 0;
+    bool counted = false;
+    bool sorted_host = false;
+    std::vector<spm_hit> host;
+    spm_scan_stats stats{};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+};
+
+#define SPM_SET_ERR(ctx, ...)                                                                                          \
+    do {                                                                                                               \
+        char _b[512];                                                                                                  \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                                                                         \
+        if (ctx)                                                                                                       \
+            (ctx)->err = _b;                                                                                           \
+        else                                                                                                           \
+            spm_hip::g_init_error = _b;                                                                                \
+    } while (0)
+
+#define SPM_HIP_CHECK(ctx, call)                                                                                       \
+    do {                                                                                                               \
+        hipError_t _e = (call);                                                                                        \
+        if (_e != hipSuccess) {                                                                                        \
+            SPM_SET_ERR(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);               \
+            return SPM_E_HIP;                                                                                          \
+        }                                                                                                              \
+    } while (0)

@@ -1,0 +1,363 @@
+// filter.hpp -- lossless pigeonhole seed filter + bit-vector verification (dna4 texts).
+//
+// Why: with one lane per pattern every text byte feeds n_patterns * ~15*NW integer ops, so the brute-force scan is
+// bound by the integer VALU four orders of magnitude below the HBM roof.  The reference itself
+// ships the way out -- a q-gram pigeonhole filter in front of verification
+// (/root/reference/libspm/libspm/matcher/pigeonhole_matcher.hpp:67-123) -- and this file is the
+// MI355X formulation of that idea, arranged so that the text is streamed ONCE at HBM speed:
+//
+//   Pigeonhole: cut needle P (|P| = m, k errors) into k+1 disjoint seeds of q = floor(m/(k+1)) symbols.  Any
+//   occurrence with <= k edits contains at least one seed unedited.
+//   Sampling:   an exact seed occurrence text[ts, ts+q) contains, for every stride S <= q-H+1, exactly one
+//   H-symbol window that starts at a text position t = 0 (mod S); it equals seed[r, r+H) for r = t-ts in [0,S).
+//   So it suffices to look at text windows at multiples of S and to index S shifted H-mers per seed.
+//   H = 16 symbols = one 32-bit key after 2-bit packing.
+//
+//   Level 1 (filter kernel, the streaming kernel): each lane loads 16 text bytes (one 16-byte coalesced load),
+//   packs them to 2 bits/base with 4 v_dot4_u32_u8, takes the previous lane's word through DPP wave_shr:1, forms
+//   the 16/S windows with v_alignbit and probes a Bloom bitmap held in LDS (cascade: later probes only run for
+//   survivors).  Survivors are looked up in an exact key table in HBM/L2 and emitted as candidates
+//   (text position, needle, needle offset) with a ballot/popc wave-aggregated append.
+//   Level 2 (verify kernel): one lane per candidate runs the same Myers recurrence as the brute kernel over the
+//   m+3k symbols around the candidate diagonal, cold-started m+k symbols before the first end position it is
+//   responsible for -- exact by the window property used for tiling.  Duplicates (several seeds of one
+//   occurrence) are removed with an atomicCAS hash set keyed by (needle, end).
+//
+// Exactness does not depend on the text being random: every true hit has a surviving seed, every candidate is
+// verified by the full recurrence.  Pathological inputs only cost time; if the candidate buffer overflows the
+// host re-runs the scan with the brute-force engine.
+#pragma once
+
+#include "brute.hpp"
+#include "common.hpp"
+#include "synth.hpp"
+
+namespace spm_hip
+{
+
+constexpr uint32_t kKeyH = 16;          // symbols per key
+constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
+
+struct candidate
+{
+    uint64_t t;   // text index of the window start
+    uint32_t val; // pattern << 11 | offset of the window inside the pattern
+    uint32_t pad;
+};
+
+struct filter_params
+{
+    const uint8_t *text;
+    uint64_t text_alloc;
+    uint64_t lo, hi;          // examine windows fully inside [lo, hi)
+    uint32_t stride;          // S in {1,2,4,8,16}
+    uint32_t bitmap_words;    // power of two, <= 32768 (128 KiB)
+    uint32_t n_probes;        // Bloom probes per key
+    uint32_t span_chunks;     // 1-KiB chunks per span
+    const uint32_t *bitmap;   // [bitmap_words]
+    const uint2 *ht;          // exact table: (key, val), val == kHtEmpty marks an empty slot
+    uint32_t ht_mask;
+    candidate *cand;
+    unsigned long long *counters; // [1] = candidate count
+    uint64_t cand_cap;
+};
+
+__host__ __device__ inline uint32_t bloom_hash(uint32_t key, uint32_t i)
+{
+    // i-th probe index (before masking).  Multiplicative hashing, distinct odd constants.
+    const uint32_t c[4] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
+    uint32_t x = key ^ (key >> (15 + i));
+    return (x * c[i & 3]) >> 7; // 25 significant bits; callers mask to the bitmap size
+}
+
+__host__ __device__ inline uint32_t ht_hash(uint32_t key)
+{
+    uint32_t x = key ^ (key >> 16);
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    return x ^ (x >> 16);
+}
+
+// text bytes 16*lane .. 16*lane+15 of a chunk -> 32-bit word, base i at bits 2i..2i+1
+__device__ __forceinline__ uint32_t pack16(const uint4 v)
+{
+    const uint32_t W = 0x40100401u; // byte weights 1,4,16,64
+    const uint32_t p0 = __builtin_amdgcn_udot4(v.x, W, 0u, false);
+    const uint32_t p1 = __builtin_amdgcn_udot4(v.y, W, 0u, false);
+    const uint32_t p2 = __builtin_amdgcn_udot4(v.z, W, 0u, false);
+    const uint32_t p3 = __builtin_amdgcn_udot4(v.w, W, 0u, false);
+    return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}
+
+__device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, uint64_t limit)
+{
+    // idx % 16 == 0.  Bytes at or beyond `limit` read as 0.
+    if (idx + 16 <= limit)
+        return *reinterpret_cast<const uint4 *>(text + idx);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 16; ++b)
+        if (idx + b < limit)
+            w[b >> 2] |= (uint32_t)text[idx + b] << (8 * (b & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int S>
+__global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
+{
+    extern __shared__ uint32_t lds[];
+    // ---- stage the Bloom bitmap in LDS (once per workgroup; the grid is persistent) ----
+    for (uint32_t i = threadIdx.x; i < P.bitmap_words; i += blockDim.x)
+        lds[i] = P.bitmap[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+    const uint32_t idx_mask = P.bitmap_words * 32 - 1;
+
+    const uint64_t base0 = P.lo & ~1023ull; // chunks are 1 KiB aligned relative to text[0]
+    const uint64_t n_chunks = (P.hi - base0 + 1023) / 1024;
+    const uint64_t span = P.span_chunks;
+    const uint64_t n_spans = (n_chunks + span - 1) / span;
+
+    constexpr int NWIN = 16 / S;
+
+    for (uint64_t sp = wave_id; sp < n_spans; sp += n_waves) {
+        const uint64_t c_begin = sp * span;
+        const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
+        // word of the lane "before lane 0": last 16 bytes of the previous chunk
+        uint32_t carry_in = 0;
+        {
+            const uint64_t cb = base0 + c_begin * 1024;
+            if (cb >= 16 && cb - 16 >= (P.lo & ~15ull) && lane == 0)
+                carry_in = pack16(load_text16(P.text, cb - 16, P.hi));
+            carry_in = __builtin_amdgcn_readfirstlane(carry_in);
+        }
+        uint4 v_next = load_text16(P.text, base0 + c_begin * 1024 + (uint64_t)lane * 16, P.hi);
+        for (uint64_t ch = c_begin; ch < c_end; ++ch) {
+            const uint64_t L = base0 + ch * 1024 + (uint64_t)lane * 16;
+            const uint4 v = v_next;
+            if (ch + 1 < c_end)
+                v_next = load_text16(P.text, L + 1024, P.hi);
+            const uint32_t w = pack16(v);
+            uint32_t prev = __builtin_amdgcn_update_dpp(0u, w, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+            if (lane == 0)
+                prev = carry_in;
+            carry_in = __builtin_amdgcn_readlane(w, 63);
+
+            // windows d = S, 2S, .., 16: text start t = L - 16 + d, key = bits [2d, 2d+32) of (w:prev)
+            uint32_t pos_mask = 0;
+#pragma unroll
+            for (int i = 0; i < NWIN; ++i) {
+                const int d = S * (i + 1);
+                const uint32_t key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
+                const uint32_t h = bloom_hash(key, 0) & idx_mask;
+                const uint32_t word = lds[h >> 5];
+                pos_mask |= ((word >> (h & 31)) & 1u) << i;
+            }
+            // cascade: further probes only for survivors
+            for (uint32_t pr = 1; pr < P.n_probes; ++pr) {
+                if (__ballot(pos_mask != 0) == 0)
+                    break;
+                uint32_t keep = 0;
+#pragma unroll
+                for (int i = 0; i < NWIN; ++i) {
+                    if (pos_mask & (1u << i)) {
+                        const int d = S * (i + 1);
+                        const uint32_t key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
+                        const uint32_t h = bloom_hash(key, pr) & idx_mask;
+                        const uint32_t word = lds[h >> 5];
+                        keep |= ((word >> (h & 31)) & 1u) << i;
+                    }
+                }
+                pos_mask = keep;
+            }
+            // survivors: exact key table
+            while (__ballot(pos_mask != 0) != 0) {
+                bool emit = false;
+                uint64_t t = 0;
+                uint32_t val = 0;
+                uint32_t key = 0;
+                uint32_t slot = 0;
+                bool probing = false;
+                if (pos_mask != 0) {
+                    const int i = __ffs(pos_mask) - 1;
+                    pos_mask &= pos_mask - 1;
+                    const int d = S * (i + 1);
+                    key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
+                    const int64_t ts = (int64_t)L - 16 + d;
+                    if (ts >= (int64_t)P.lo && (uint64_t)ts + kKeyH <= P.hi) {
+                        t = (uint64_t)ts;
+                        slot = ht_hash(key) & P.ht_mask;
+                        probing = true;
+                    }
+                }
+                while (__ballot(probing) != 0) {
+                    emit = false;
+                    if (probing) {
+                        const uint2 e = P.ht[slot];
+                        if (e.y == kHtEmpty) {
+                            probing = false;
+                        } else {
+                            if (e.x == key) {
+                                emit = true;
+                                val = e.y;
+                            }
+                            slot = (slot + 1) & P.ht_mask;
+                        }
+                    }
+                    const uint64_t m = __ballot(emit);
+                    if (m != 0) {
+                        const uint32_t n = __popcll(m);
+                        const int leader = __ffsll((unsigned long long)m) - 1;
+                        unsigned long long base = 0;
+                        if ((int)lane == leader)
+                            base = atomicAdd(&P.counters[1], (unsigned long long)n);
+                        base = __shfl(base, leader);
+                        if (emit) {
+                            const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
+                            if (idx < P.cand_cap) {
+                                candidate c;
+                                c.t = t;
+                                c.val = val;
+                                c.pad = 0;
+                                P.cand[idx] = c;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// verification: one lane per candidate
+// ---------------------------------------------------------------------------------------------------
+struct verify_params
+{
+    const uint8_t *text;
+    uint64_t ctx_begin;  // first symbol of the haystack that may be consumed
+    uint64_t scan_begin; // owned: last symbol index in [scan_begin, scan_end)
+    uint64_t scan_end;
+    uint64_t pos_offset;
+    const candidate *cand;
+    const unsigned long long *counters; // [1] candidates
+    uint64_t cand_cap;
+    const uint64_t *peq64; // [pattern][4][NB] unshifted 64-bit Peq words
+    const int32_t *m;      // per pattern
+    const int32_t *k;
+    uint32_t report_begin; // 1: exact matchers report begin = end - m
+    uint32_t pad;
+    unsigned long long *seen; // hash set of (pattern << 40 | end)
+    uint32_t seen_mask;
+    spm_hit *hits;
+    unsigned long long *hit_counter; // counters[0]
+    uint64_t hit_cap;
+    unsigned long long *overflow; // counters[2]
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
+{
+    unsigned long long n_cand = P.counters[1];
+    if (n_cand > P.cand_cap)
+        n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < n_cand; ci += stride) {
+        const candidate c = P.cand[ci];
+        const uint32_t pat = c.val >> 11;
+        const int64_t x = c.val & 0x7FF;
+        const int64_t m = P.m[pat];
+        const int64_t k = P.k[pat];
+        const int64_t d = (int64_t)c.t - x; // diagonal: needle position 0 <-> text index d
+        // exclusive end positions this candidate answers for: e in [d+m-k, d+m+k]
+        int64_t e_lo = d + m - k;
+        int64_t e_hi = d + m + k;
+        // ownership: last symbol e-1 in [scan_begin, scan_end)
+        if (e_lo < (int64_t)P.scan_begin + 1)
+            e_lo = (int64_t)P.scan_begin + 1;
+        if (e_hi > (int64_t)P.scan_end)
+            e_hi = (int64_t)P.scan_end;
+        if (e_lo > e_hi)
+            continue;
+        // cold start m+k symbols before the first end position (or at the haystack start)
+        int64_t ws = e_lo - (m + k);
+        if (ws < (int64_t)P.ctx_begin)
+            ws = (int64_t)P.ctx_begin;
+        const uint64_t *peq = P.peq64 + (size_t)pat * 4 * NB;
+        uint64_t VP[NB], VN[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int64_t rows = m - 64 * b;
+            VP[b] = rows >= 64 ? ~0ull : (rows <= 0 ? 0ull : ((1ull << rows) - 1));
+            VN[b] = 0;
+        }
+        int32_t score = (int32_t)m;
+        const int lastb = (int)((m - 1) >> 6);
+        const int lastbit = (int)((m - 1) & 63);
+        for (int64_t p = ws; p < e_hi; ++p) {
+            const uint32_t sym = P.text[p] & 3;
+            uint64_t carry = 0, hp_c = 0, hn_c = 0;
+            uint64_t HPl = 0, HNl = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const uint64_t eq = peq[sym * NB + b];
+                const uint64_t X = eq | VN[b];
+                const uint64_t t1 = X & VP[b];
+                const uint64_t s1 = VP[b] + t1;
+                const uint64_t c1 = s1 < VP[b];
+                const uint64_t s2 = s1 + carry;
+                const uint64_t c2 = s2 < s1;
+                carry = c1 | c2;
+                const uint64_t D0 = (s2 ^ VP[b]) | X;
+                const uint64_t HN = VP[b] & D0;
+                const uint64_t HP = VN[b] | ~(VP[b] | D0);
+                const uint64_t Xs = (HP << 1) | hp_c;
+                const uint64_t Ts = (HN << 1) | hn_c;
+                hp_c = HP >> 63;
+                hn_c = HN >> 63;
+                VN[b] = Xs & D0;
+                VP[b] = Ts | ~(Xs | D0);
+                if (b == lastb) {
+                    HPl = HP;
+                    HNl = HN;
+                }
+            }
+            score += (int32_t)((HPl >> lastbit) & 1) - (int32_t)((HNl >> lastbit) & 1);
+            const int64_t e = p + 1;
+            if (score <= (int32_t)k && e >= e_lo) {
+                // dedupe across the seeds of one occurrence
+                const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
+                uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
+                bool fresh = false;
+                for (uint32_t tries = 0; tries <= P.seen_mask; ++tries) {
+                    const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
+                    if (old == ~0ull) {
+                        fresh = true;
+                        break;
+                    }
+                    if (old == key)
+                        break;
+                    slot = (slot + 1) & P.seen_mask;
+                    if (tries == P.seen_mask)
+                        atomicAdd(P.overflow, 1ull);
+                }
+                if (fresh) {
+                    const unsigned long long idx = atomicAdd(P.hit_counter, 1ull);
+                    if (idx < P.hit_cap) {
+                        spm_hit h;
+                        h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
+                        h.pattern = pat;
+                        h.score = score;
+                        P.hits[idx] = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace spm_hip

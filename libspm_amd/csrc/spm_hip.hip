@@ -1,0 +1,1087 @@
+// spm_hip.hip -- C ABI of libspm_hip.so (see include/spm_hip.h) and the host side of the scan engines.
+//
+// Host responsibilities (what the reference does in its matcher constructors and in
+// seqan_pattern_base::operator(), /root/reference/libspm/libspm/matcher/seqan_pattern_base.hpp:40-71):
+//   * build the per-needle bit-mask tables once (patterns_create)  -- [upstream] _patternFirstInit
+//   * choose engine, tile the haystack, launch, collect hits       -- the find loop
+// MI355X only; no CPU scan path exists in this library: if HIP fails the call fails.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "brute.hpp"
+#include "common.hpp"
+#include "filter.hpp"
+#include "synth.hpp"
+
+namespace spm_hip
+{
+thread_local std::string g_init_error;
+}
+
+using namespace spm_hip;
+
+// ----------------------------------------------------------------------------------------------------
+// pattern set
+// ----------------------------------------------------------------------------------------------------
+struct filter_index
+{
+    bool ok = false;
+    uint32_t stride = 0;
+    uint32_t bitmap_words = 0;
+    uint32_t n_probes = 0;
+    uint32_t ht_mask = 0;
+    uint64_t n_keys = 0;
+    uint32_t *d_bitmap = nullptr;
+    uint2 *d_ht = nullptr;
+};
+
+struct spm_patterns
+{
+    spm_ctx *ctx = nullptr;
+    int algo = 0;
+    uint32_t n = 0;
+    uint32_t sigma = 4;
+    std::vector<uint8_t> ranks;
+    std::vector<uint32_t> offsets;
+    std::vector<int32_t> m, k; // padded to n_groups*64
+    uint32_t n_groups = 0;
+    uint32_t max_m = 0;
+    uint32_t max_window = 0;
+    uint32_t max_k = 0;
+    uint32_t NW = 1;   // 32-bit words per needle in the brute kernels (power of two)
+    uint32_t NB64 = 1; // 64-bit words per needle in the verify kernel (power of two)
+    bool is_myers() const { return algo == SPM_ALGO_MYERS || algo == SPM_ALGO_MYERS_PREFIX; }
+    // device
+    uint32_t *d_peq = nullptr; // [group][sigma+1][NW][64]
+    uint32_t *d_hp0 = nullptr; // prefix: [group][NW][64]
+    int32_t *d_m = nullptr;
+    int32_t *d_k = nullptr;
+    uint64_t *d_peq64 = nullptr; // verify: [pattern][4][NB64]
+    filter_index fidx;
+};
+
+static uint32_t next_pow2(uint32_t x)
+{
+    uint32_t p = 1;
+    while (p < x)
+        p <<= 1;
+    return p;
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
+{
+    filter_index &F = ps->fidx;
+    F.ok = false;
+    if (ps->sigma != 4 || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 || ps->n >= (1u << 21))
+        return SPM_OK;
+    uint32_t qmin = 0xFFFFFFFFu;
+    for (uint32_t p = 0; p < ps->n; ++p) {
+        const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
+        if (m == 0 || m > 2047)
+            return SPM_OK;
+        qmin = std::min(qmin, m / (k + 1));
+    }
+    if (qmin < kKeyH)
+        return SPM_OK;
+    uint32_t S = 1;
+    while (S * 2 <= 16 && S * 2 <= qmin - (kKeyH - 1))
+        S *= 2;
+    const int force_s = env_int("SPM_HIP_FILTER_STRIDE", 0);
+    if (force_s > 0 && (uint32_t)force_s <= S)
+        S = (uint32_t)force_s;
+
+    struct kv
+    {
+        uint32_t key, val;
+    };
+    std::vector<kv> keys;
+    for (uint32_t p = 0; p < ps->n; ++p) {
+        const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
+        const uint32_t q = m / (k + 1);
+        const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
+        for (uint32_t j = 0; j <= k; ++j) {
+            const uint32_t o = j * q;
+            for (uint32_t r = 0; r < S; ++r) {
+                // window seed[r, r+16) -- inside the seed because S <= q - 15
+                uint32_t key = 0;
+                for (uint32_t i = 0; i < kKeyH; ++i)
+                    key |= (uint32_t)(pat[o + r + i] & 3) << (2 * i);
+                keys.push_back({key, (p << 11) | (o + r)});
+            }
+        }
+    }
+    F.n_keys = keys.size();
+    const uint64_t max_keys = (uint64_t)env_int("SPM_HIP_FILTER_MAX_KEYS", 1 << 18);
+    if (F.n_keys == 0 || F.n_keys > max_keys)
+        return SPM_OK; // TODO(next): split the needle set into sub-batches, one text pass each
+    F.stride = S;
+    F.n_probes = (uint32_t)std::max(1, std::min(4, env_int("SPM_HIP_FILTER_PROBES", 4)));
+    uint64_t want_bits = F.n_keys * 32;
+    uint32_t words = 1024;
+    while ((uint64_t)words * 32 < want_bits && words < 32768)
+        words <<= 1;
+    const int force_w = env_int("SPM_HIP_FILTER_BITMAP_WORDS", 0);
+    if (force_w >= 256 && force_w <= 32768 && (force_w & (force_w - 1)) == 0)
+        words = (uint32_t)force_w;
+    F.bitmap_words = words;
+    std::vector<uint32_t> bitmap(words, 0);
+    const uint32_t idx_mask = words * 32 - 1;
+    for (const kv &e : keys)
+        for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
+            const uint32_t h = bloom_hash(e.key, pr) & idx_mask;
+            bitmap[h >> 5] |= 1u << (h & 31);
+        }
+    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_keys * 2));
+    F.ht_mask = ht_size - 1;
+    std::vector<uint2> ht(ht_size, make_uint2(0, kHtEmpty));
+    for (const kv &e : keys) {
+        uint32_t slot = ht_hash(e.key) & F.ht_mask;
+        while (ht[slot].y != kHtEmpty)
+            slot = (slot + 1) & F.ht_mask;
+        ht[slot] = make_uint2(e.key, e.val);
+    }
+    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_bitmap, words * sizeof(uint32_t)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint2)));
+    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_bitmap, bitmap.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht, ht.data(), ht_size * sizeof(uint2), hipMemcpyHostToDevice));
+    F.ok = true;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ranks_concat, const uint32_t *offsets,
+                                       uint32_t n_patterns, const uint16_t *k, uint32_t sigma, spm_patterns **out)
+{
+    if (!ctx || !out || (n_patterns && (!offsets || !ranks_concat)) || sigma < 2 || sigma > 255 || algo < 0 ||
+        algo > SPM_ALGO_HORSPOOL) {
+        SPM_SET_ERR(ctx, "spm_hip_patterns_create: invalid argument");
+        return SPM_E_INVALID;
+    }
+    SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<spm_patterns> ps(new spm_patterns);
+    ps->ctx = ctx;
+    ps->algo = algo;
+    ps->n = n_patterns;
+    ps->sigma = sigma;
+    ps->offsets.assign(offsets, offsets + n_patterns + 1);
+    ps->ranks.assign(ranks_concat, ranks_concat + (n_patterns ? offsets[n_patterns] : 0));
+    ps->n_groups = std::max(1u, (n_patterns + 63) / 64);
+    ps->m.assign((size_t)ps->n_groups * 64, 0);
+    ps->k.assign((size_t)ps->n_groups * 64, -1);
+    for (uint32_t p = 0; p < n_patterns; ++p) {
+        if (offsets[p + 1] < offsets[p]) {
+            SPM_SET_ERR(ctx, "spm_hip_patterns_create: offsets not ascending");
+            return SPM_E_INVALID;
+        }
+        const uint32_t m = offsets[p + 1] - offsets[p];
+        if (m > SPM_MAX_NEEDLE) {
+            SPM_SET_ERR(ctx, "needle %u has %u symbols; limit is %u", p, m, SPM_MAX_NEEDLE);
+            return SPM_E_UNSUPPORTED;
+        }
+        const uint32_t kk = (ps->is_myers() && k) ? k[p] : 0;
+        ps->m[p] = (int32_t)m;
+        ps->k[p] = (int32_t)kk;
+        ps->max_m = std::max(ps->max_m, m);
+        ps->max_k = std::max(ps->max_k, kk);
+        ps->max_window = std::max(ps->max_window, m + kk);
+    }
+    ps->NW = next_pow2(std::max(1u, (ps->max_m + 31) / 32));
+    ps->NB64 = next_pow2(std::max(1u, (ps->max_m + 63) / 64));
+    const uint32_t NW = ps->NW, rows = sigma + 1;
+    const bool myers = ps->is_myers();
+
+    // ---- brute tables: [group][row][word][lane], needles top-aligned (see brute.hpp) ----
+    std::vector<uint32_t> peq((size_t)ps->n_groups * rows * NW * 64, 0);
+    std::vector<uint32_t> hp0;
+    if (algo == SPM_ALGO_MYERS_PREFIX)
+        hp0.assign((size_t)ps->n_groups * NW * 64, 0);
+    for (uint32_t g = 0; g < ps->n_groups; ++g)
+        for (uint32_t l = 0; l < 64; ++l) {
+            const uint32_t p = g * 64 + l;
+            const uint32_t m = p < n_patterns ? (uint32_t)ps->m[p] : 0;
+            const uint32_t off = NW * 32 - m;
+            auto word = [&](uint32_t row, uint32_t w) -> uint32_t & {
+                return peq[(((size_t)g * rows + row) * NW + w) * 64 + l];
+            };
+            if (myers) {
+                // Peq: bit set = match.  wildcard rows (bits < off) match every symbol, also the invalid one
+                if (m > 0)
+                    for (uint32_t row = 0; row < rows; ++row)
+                        for (uint32_t b = 0; b < off; ++b)
+                            word(row, b / 32) |= 1u << (b % 32);
+                for (uint32_t j = 0; j < m; ++j) {
+                    const uint8_t c = ps->ranks[ps->offsets[p] + j];
+                    if (c < sigma)
+                        word(c, (off + j) / 32) |= 1u << ((off + j) % 32);
+                }
+                if (algo == SPM_ALGO_MYERS_PREFIX && m > 0)
+                    hp0[((size_t)g * NW + off / 32) * 64 + l] = 1u << (off % 32);
+            } else {
+                // Shift-Or masks: bit CLEAR = match; wildcard bits clear for every row
+                for (uint32_t row = 0; row < rows; ++row)
+                    for (uint32_t w = 0; w < NW; ++w)
+                        word(row, w) = 0xFFFFFFFFu;
+                if (m > 0)
+                    for (uint32_t row = 0; row < rows; ++row)
+                        for (uint32_t b = 0; b < off; ++b)
+                            word(row, b / 32) &= ~(1u << (b % 32));
+                for (uint32_t j = 0; j < m; ++j) {
+                    const uint8_t c = ps->ranks[ps->offsets[p] + j];
+                    if (c < sigma)
+                        word(c, (off + j) / 32) &= ~(1u << ((off + j) % 32));
+                }
+            }
+        }
+    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq, peq.size() * sizeof(uint32_t)));
+    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq, peq.data(), peq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!hp0.empty()) {
+        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_hp0, hp0.size() * sizeof(uint32_t)));
+        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_hp0, hp0.data(), hp0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_m, ps->m.size() * sizeof(int32_t)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_k, ps->k.size() * sizeof(int32_t)));
+    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_m, ps->m.data(), ps->m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+
+    // ---- filter engine tables ----
+    if (sigma == 4 && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
+        const uint32_t NB = ps->NB64;
+        std::vector<uint64_t> p64((size_t)n_patterns * 4 * NB, 0);
+        for (uint32_t p = 0; p < n_patterns; ++p)
+            for (uint32_t j = 0; j < (uint32_t)ps->m[p]; ++j) {
+                const uint8_t c = ps->ranks[ps->offsets[p] + j];
+                if (c < 4)
+                    p64[((size_t)p * 4 + c) * NB + j / 64] |= 1ull << (j % 64);
+            }
+        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq64, p64.size() * sizeof(uint64_t)));
+        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq64, p64.data(), p64.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        int rc = build_filter_index(ctx, ps.get());
+        if (rc != SPM_OK)
+            return rc;
+    }
+    *out = ps.release();
+    return SPM_OK;
+}
+
+extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
+{
+    if (!p)
+        return;
+    hipFree(p->d_peq);
+    hipFree(p->d_hp0);
+    hipFree(p->d_m);
+    hipFree(p->d_k);
+    hipFree(p->d_peq64);
+    hipFree(p->fidx.d_bitmap);
+    hipFree(p->fidx.d_ht);
+    delete p;
+}
+
+extern "C" uint64_t spm_hip_patterns_window_size(const spm_patterns *p, uint32_t pattern)
+{
+    if (!p || pattern >= p->n || p->m[pattern] == 0)
+        return 0;
+    return (uint64_t)p->m[pattern] + (p->is_myers() ? (uint64_t)p->k[pattern] : 0);
+}
+
+extern "C" int spm_hip_patterns_filterable(const spm_patterns *p) { return p && p->fidx.ok ? 1 : 0; }
+
+// ---- state blobs -------------------------------------------------------------------------------------
+static uint32_t abi_words(const spm_patterns *p)
+{
+    return p->is_myers() ? std::max(1u, (p->max_m + 63) / 64) : std::max(1u, (p->max_m + 31) / 32);
+}
+
+extern "C" size_t spm_hip_patterns_state_stride(const spm_patterns *p)
+{
+    if (!p)
+        return 0;
+    const uint32_t nw = abi_words(p);
+    return p->is_myers() ? 8 + (size_t)16 * nw : 8 + (size_t)4 * ((nw + 1) & ~1u);
+}
+
+static void set_bits(std::vector<uint32_t> &v, uint32_t lo, uint32_t hi)
+{
+    for (uint32_t b = lo; b < hi; ++b)
+        v[b / 32] |= 1u << (b % 32);
+}
+
+extern "C" int spm_hip_patterns_state_init(const spm_patterns *p, void *state)
+{
+    if (!p || !state)
+        return SPM_E_INVALID;
+    const size_t stride = spm_hip_patterns_state_stride(p);
+    const uint32_t nw = abi_words(p);
+    memset(state, 0, stride * p->n);
+    for (uint32_t i = 0; i < p->n; ++i) {
+        uint8_t *rec = (uint8_t *)state + stride * i;
+        const uint32_t m = (uint32_t)p->m[i];
+        if (p->is_myers()) {
+            int32_t score = (int32_t)m;
+            memcpy(rec, &score, 4);
+            memcpy(rec + 4, &nw, 4);
+            uint64_t *vp = (uint64_t *)(rec + 8);
+            for (uint32_t b = 0; b < m; ++b)
+                vp[b / 64] |= 1ull << (b % 64);
+        } else {
+            memcpy(rec, &nw, 4);
+            uint32_t *r = (uint32_t *)(rec + 8);
+            for (uint32_t w = 0; w < nw; ++w)
+                r[w] = 0xFFFFFFFFu;
+        }
+    }
+    return SPM_OK;
+}
+
+// ABI state -> internal [group][rows][64] layout (top-aligned) and back
+static void state_to_internal(const spm_patterns *p, const void *state, std::vector<uint32_t> &out)
+{
+    const uint32_t NW = p->NW, nw = abi_words(p);
+    const size_t stride = spm_hip_patterns_state_stride(p);
+    const uint32_t rows = p->is_myers() ? 2 * NW + 1 : NW;
+    out.assign((size_t)p->n_groups * rows * 64, 0);
+    for (uint32_t i = 0; i < p->n_groups * 64; ++i) {
+        const uint32_t g = i / 64, l = i % 64;
+        const uint32_t m = i < p->n ? (uint32_t)p->m[i] : 0;
+        const uint32_t off = NW * 32 - m;
+        auto at = [&](uint32_t row) -> uint32_t & { return out[((size_t)g * rows + row) * 64 + l]; };
+        if (i >= p->n || m == 0) {
+            if (p->is_myers())
+                at(2 * NW) = 0x3FFFFFFF; // score that never reaches k
+            else
+                for (uint32_t w = 0; w < NW; ++w)
+                    at(w) = 0xFFFFFFFFu;
+            continue;
+        }
+        const uint8_t *rec = (const uint8_t *)state + stride * i;
+        if (p->is_myers()) {
+            int32_t score;
+            memcpy(&score, rec, 4);
+            const uint64_t *vp = (const uint64_t *)(rec + 8);
+            const uint64_t *vn = vp + nw;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t b = off + j;
+                if ((vp[j / 64] >> (j % 64)) & 1)
+                    at(b / 32) |= 1u << (b % 32);
+                if ((vn[j / 64] >> (j % 64)) & 1)
+                    at(NW + b / 32) |= 1u << (b % 32);
+            }
+            at(2 * NW) = (uint32_t)score;
+        } else {
+            const uint32_t *r = (const uint32_t *)(rec + 8);
+            for (uint32_t w = 0; w < NW; ++w)
+                at(w) = 0;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t b = off + j;
+                if ((r[j / 32] >> (j % 32)) & 1)
+                    at(b / 32) |= 1u << (b % 32);
+            }
+        }
+    }
+}
+
+static void state_from_internal(const spm_patterns *p, const std::vector<uint32_t> &in, void *state)
+{
+    const uint32_t NW = p->NW, nw = abi_words(p);
+    const size_t stride = spm_hip_patterns_state_stride(p);
+    const uint32_t rows = p->is_myers() ? 2 * NW + 1 : NW;
+    memset(state, 0, stride * p->n);
+    for (uint32_t i = 0; i < p->n; ++i) {
+        const uint32_t g = i / 64, l = i % 64;
+        const uint32_t m = (uint32_t)p->m[i];
+        const uint32_t off = NW * 32 - m;
+        auto at = [&](uint32_t row) -> uint32_t { return in[((size_t)g * rows + row) * 64 + l]; };
+        uint8_t *rec = (uint8_t *)state + stride * i;
+        if (p->is_myers()) {
+            int32_t score = m ? (int32_t)at(2 * NW) : 0;
+            memcpy(rec, &score, 4);
+            memcpy(rec + 4, &nw, 4);
+            uint64_t *vp = (uint64_t *)(rec + 8);
+            uint64_t *vn = vp + nw;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t b = off + j;
+                if ((at(b / 32) >> (b % 32)) & 1)
+                    vp[j / 64] |= 1ull << (j % 64);
+                if ((at(NW + b / 32) >> (b % 32)) & 1)
+                    vn[j / 64] |= 1ull << (j % 64);
+            }
+        } else {
+            memcpy(rec, &nw, 4);
+            uint32_t *r = (uint32_t *)(rec + 8);
+            for (uint32_t w = 0; w < nw; ++w)
+                r[w] = 0xFFFFFFFFu; // bits >= |P| stay set, as in SeqAn's masks
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t b = off + j;
+                if (!((at(b / 32) >> (b % 32)) & 1))
+                    r[j / 32] &= ~(1u << (j % 32));
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// context / text
+// ----------------------------------------------------------------------------------------------------
+extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
+{
+    if (!out) {
+        SPM_SET_ERR((spm_ctx *)nullptr, "spm_hip_init: out == NULL");
+        return SPM_E_INVALID;
+    }
+    spm_ctx *none = nullptr;
+    int n_dev = 0;
+    SPM_HIP_CHECK(none, hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) {
+        SPM_SET_ERR(none, "spm_hip_init: device %d not available (%d HIP devices)", device, n_dev);
+        return SPM_E_INVALID;
+    }
+    SPM_HIP_CHECK(none, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPM_HIP_CHECK(none, hipGetDeviceProperties(&prop, device));
+    std::unique_ptr<spm_ctx> ctx(new spm_ctx);
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        SPM_HIP_CHECK(none, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    *out = ctx.release();
+    return SPM_OK;
+}
+
+extern "C" void spm_hip_destroy(spm_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream)
+        hipStreamDestroy(ctx->stream);
+    hipFree(ctx->d_scratch);
+    delete ctx;
+}
+
+extern "C" const char *spm_hip_last_error(const spm_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : spm_hip::g_init_error.c_str();
+}
+
+extern "C" int spm_hip_synchronize(spm_ctx *ctx)
+{
+    if (!ctx)
+        return SPM_E_INVALID;
+    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPM_OK;
+}
+
+static int text_alloc(spm_ctx *ctx, uint64_t n, uint32_t sigma, spm_text **out)
+{
+    std::unique_ptr<spm_text> t(new spm_text);
+    t->ctx = ctx;
+    t->n = n;
+    t->sigma = sigma;
+    t->alloc = ((n + 1023) & ~1023ull) + 1024; // the kernels never read past `n`, padding is slack only
+    t->owned = true;
+    SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SPM_HIP_CHECK(ctx, hipMalloc(&t->d, t->alloc));
+    *out = t.release();
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_text_upload(spm_ctx *ctx, const uint8_t *ranks, uint64_t n, uint32_t sigma, spm_text **out)
+{
+    if (!ctx || !out || (n && !ranks) || sigma < 2 || sigma > 255) {
+        SPM_SET_ERR(ctx, "spm_hip_text_upload: invalid argument");
+        return SPM_E_INVALID;
+    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (ranks[i] >= sigma) {
+            SPM_SET_ERR(ctx, "spm_hip_text_upload: symbol %u at %llu is not a rank < sigma=%u", ranks[i],
+                        (unsigned long long)i, sigma);
+            return SPM_E_INVALID;
+        }
+    spm_text *t = nullptr;
+    int rc = text_alloc(ctx, n, sigma, &t);
+    if (rc != SPM_OK)
+        return rc;
+    if (n) {
+        hipError_t e = hipMemcpyAsync(t->d, ranks, n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            SPM_SET_ERR(ctx, "text upload failed: %s", hipGetErrorString(e));
+            spm_hip_text_destroy(t);
+            return SPM_E_HIP;
+        }
+    }
+    *out = t;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_t n, uint32_t sigma, spm_text **out)
+{
+    if (!ctx || !out || (n && !device_ranks) || ((uintptr_t)device_ranks & 15) || sigma < 2 || sigma > 255) {
+        SPM_SET_ERR(ctx, "spm_hip_text_wrap: invalid argument (pointer must be 16-byte aligned)");
+        return SPM_E_INVALID;
+    }
+    spm_text *t = new spm_text;
+    t->ctx = ctx;
+    t->d = (uint8_t *)device_ranks;
+    t->n = n;
+    t->alloc = n;
+    t->sigma = sigma;
+    t->owned = false;
+    *out = t;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, spm_text **out)
+{
+    if (!ctx || !out || (global_begin & 31)) {
+        SPM_SET_ERR(ctx, "spm_hip_text_generate: global_begin must be a multiple of 32");
+        return SPM_E_INVALID;
+    }
+    spm_text *t = nullptr;
+    int rc = text_alloc(ctx, n, 4, &t);
+    if (rc != SPM_OK)
+        return rc;
+    if (n) {
+        const uint64_t n_words = (n + 31) / 32;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, (uint64_t)ctx->n_cu * 16);
+        hipLaunchKernelGGL(synth_text_kernel, dim3(grid), dim3(256), 0, ctx->stream, t->d, seed, global_begin, n);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            SPM_SET_ERR(ctx, "text generate failed: %s", hipGetErrorString(e));
+            spm_hip_text_destroy(t);
+            return SPM_E_HIP;
+        }
+    }
+    *out = t;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_text_download(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t n, uint8_t *dst)
+{
+    if (!ctx || !text || begin + n > text->n || (n && !dst)) {
+        SPM_SET_ERR(ctx, "spm_hip_text_download: invalid argument");
+        return SPM_E_INVALID;
+    }
+    if (n) {
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(dst, text->d + begin, n, hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SPM_OK;
+}
+
+extern "C" uint64_t spm_hip_text_length(const spm_text *t) { return t ? t->n : 0; }
+extern "C" const void *spm_hip_text_device_ptr(const spm_text *t) { return t ? t->d : nullptr; }
+
+extern "C" void spm_hip_text_destroy(spm_text *t)
+{
+    if (!t)
+        return;
+    if (t->owned)
+        hipFree(t->d);
+    delete t;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// scan
+// ----------------------------------------------------------------------------------------------------
+namespace
+{
+
+struct scan_args
+{
+    spm_ctx *ctx;
+    const spm_text *text;
+    uint64_t begin, end, ctx_begin;
+    const spm_patterns *ps;
+    spm_scan_opts opts;
+    const void *state_in;
+    void *state_out;
+    spm_hits *hits;
+};
+
+template <int NW>
+void launch_brute_nw(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds,
+                     hipStream_t stream)
+{
+    if (ps->algo == SPM_ALGO_MYERS) {
+        hipFuncSetAttribute((const void *)myers_brute_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        hipLaunchKernelGGL((myers_brute_kernel<NW, false>), grid, block, lds, stream, P);
+    } else if (ps->algo == SPM_ALGO_MYERS_PREFIX) {
+        hipFuncSetAttribute((const void *)myers_brute_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        hipLaunchKernelGGL((myers_brute_kernel<NW, true>), grid, block, lds, stream, P);
+    } else {
+        hipFuncSetAttribute((const void *)shiftor_brute_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        hipLaunchKernelGGL((shiftor_brute_kernel<NW>), grid, block, lds, stream, P);
+    }
+}
+
+void launch_brute(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds, hipStream_t s)
+{
+    switch (ps->NW) {
+    case 1: launch_brute_nw<1>(ps, P, grid, block, lds, s); break;
+    case 2: launch_brute_nw<2>(ps, P, grid, block, lds, s); break;
+    case 4: launch_brute_nw<4>(ps, P, grid, block, lds, s); break;
+    case 8: launch_brute_nw<8>(ps, P, grid, block, lds, s); break;
+    case 16: launch_brute_nw<16>(ps, P, grid, block, lds, s); break;
+    case 32: launch_brute_nw<32>(ps, P, grid, block, lds, s); break;
+    default: launch_brute_nw<64>(ps, P, grid, block, lds, s); break;
+    }
+}
+
+template <int NB>
+void launch_verify_nb(const verify_params &V, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((verify_kernel<NB>), grid, dim3(256), 0, s, V);
+}
+
+void launch_verify(uint32_t NB, const verify_params &V, dim3 grid, hipStream_t s)
+{
+    switch (NB) {
+    case 1: launch_verify_nb<1>(V, grid, s); break;
+    case 2: launch_verify_nb<2>(V, grid, s); break;
+    case 4: launch_verify_nb<4>(V, grid, s); break;
+    case 8: launch_verify_nb<8>(V, grid, s); break;
+    case 16: launch_verify_nb<16>(V, grid, s); break;
+    default: launch_verify_nb<32>(V, grid, s); break;
+    }
+}
+
+int ensure_scratch(spm_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes)
+        return SPM_OK;
+    if (ctx->d_scratch) {
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        SPM_HIP_CHECK(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return SPM_OK;
+}
+
+// one brute-force pass; `report` = false suppresses hits (state-only pass)
+int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_begin, const uint32_t *d_state_in,
+              uint32_t *d_state_out, bool report, bool single_tile)
+{
+    spm_ctx *ctx = A.ctx;
+    const spm_patterns *ps = A.ps;
+    brute_params P{};
+    P.text = A.text->d;
+    P.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
+    P.scan_begin = begin;
+    P.scan_end = end;
+    P.ctx_begin = ctx_begin;
+    P.pos_offset = A.opts.pos_offset;
+    P.n_groups = ps->n_groups;
+    P.warm = ps->max_window > 0 ? ps->max_window - 1 : 0;
+    P.sigma = ps->sigma;
+    P.has_state = d_state_in ? 1 : 0;
+    P.peq = ps->d_peq;
+    P.hp0 = ps->d_hp0;
+    P.m = ps->d_m;
+    P.k = ps->d_k;
+    P.state_in = d_state_in;
+    P.state_out = d_state_out;
+    P.hits = A.hits->d_hits;
+    P.counters = A.hits->d_count + (report ? 0 : 3); // a state-only pass counts into a dummy slot
+    P.hit_cap = report ? A.hits->cap : 0;
+
+    const size_t lds_per_wave = (size_t)(ps->sigma + 1) * ps->NW * 64 * sizeof(uint32_t);
+    uint32_t wpw = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / lds_per_wave));
+    const size_t lds = lds_per_wave * wpw;
+    if (lds > 160 * 1024) {
+        SPM_SET_ERR(ctx, "needle set needs %zu bytes of LDS per wave (sigma=%u, %u words); limit 160 KiB", lds,
+                    ps->sigma, ps->NW);
+        return SPM_E_UNSUPPORTED;
+    }
+    const uint64_t range = end - begin;
+    uint32_t grid = ps->n_groups * std::max(1u, (uint32_t)(ctx->n_cu * 8) / (ps->n_groups * 1));
+    grid = std::max(grid, ps->n_groups);
+    // grid counts workgroups; keep (grid * wpw) % n_groups == 0 so that a wave keeps its needle group in LDS
+    const uint64_t n_waves = (uint64_t)grid * wpw;
+    uint64_t tile;
+    if (single_tile || ps->algo == SPM_ALGO_MYERS_PREFIX) {
+        tile = (range + 3) & ~3ull;
+    } else {
+        const uint64_t min_tile = std::max<uint64_t>(2048, (((uint64_t)P.warm * 16) + 255) & ~255ull);
+        tile = (range * ps->n_groups) / (n_waves * 4) + 1;
+        tile = (tile + 255) & ~255ull;
+        tile = std::max(tile, min_tile);
+        tile = std::min<uint64_t>(tile, 1u << 20);
+    }
+    if (tile == 0)
+        tile = 4;
+    P.tile = (uint32_t)std::min<uint64_t>(tile, 0xFFFFFF00u);
+    P.n_tiles = (uint32_t)std::max<uint64_t>(1, (range + P.tile - 1) / P.tile);
+    if (single_tile && P.n_tiles != 1) {
+        SPM_SET_ERR(ctx, "internal: single-tile pass over %llu symbols", (unsigned long long)range);
+        return SPM_E_INVALID;
+    }
+    const uint64_t n_items = (uint64_t)P.n_tiles * P.n_groups;
+    const uint32_t need_wg = (uint32_t)std::min<uint64_t>((n_items + wpw - 1) / wpw, grid);
+    // shrinking the grid must keep the group<->wave affinity: round up to a multiple of n_groups when possible
+    uint32_t launch_grid = need_wg;
+    if (launch_grid < grid) {
+        const uint32_t q = (launch_grid + ps->n_groups - 1) / ps->n_groups * ps->n_groups;
+        launch_grid = std::min(grid, std::max(q, 1u));
+    }
+    launch_brute(ps, P, dim3(launch_grid), dim3(64 * wpw), lds, ctx->stream);
+    SPM_HIP_CHECK(ctx, hipGetLastError());
+    A.hits->stats.main_launches++;
+    return SPM_OK;
+}
+
+int run_filter(const scan_args &A)
+{
+    spm_ctx *ctx = A.ctx;
+    const spm_patterns *ps = A.ps;
+    const filter_index &F = ps->fidx;
+    spm_hits *H = A.hits;
+    // scratch: candidates + dedupe set
+    const uint64_t kmax = ps->max_k;
+    uint64_t seen_slots = 1u << 20;
+    uint64_t cand_cap = (seen_slots / 2) / (2 * kmax + 1);
+    cand_cap = std::max<uint64_t>(cand_cap, 1024);
+    const int cc = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
+    if (cc > 0)
+        cand_cap = (uint64_t)cc;
+    while (seen_slots / 2 < cand_cap * (2 * kmax + 1))
+        seen_slots <<= 1;
+    const size_t cand_bytes = cand_cap * sizeof(candidate);
+    const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
+    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes);
+    if (rc != SPM_OK)
+        return rc;
+    candidate *d_cand = (candidate *)ctx->d_scratch;
+    unsigned long long *d_seen = (unsigned long long *)((uint8_t *)ctx->d_scratch + cand_bytes);
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
+
+    filter_params P{};
+    P.text = A.text->d;
+    P.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
+    // windows that can belong to an occurrence whose last symbol is owned
+    const uint64_t reach = ps->max_window;
+    P.lo = A.begin >= A.ctx_begin + reach ? A.begin - reach : A.ctx_begin;
+    P.hi = A.end;
+    P.stride = F.stride;
+    P.bitmap_words = F.bitmap_words;
+    P.n_probes = F.n_probes;
+    P.bitmap = F.d_bitmap;
+    P.ht = F.d_ht;
+    P.ht_mask = F.ht_mask;
+    P.cand = d_cand;
+    P.counters = H->d_count;
+    P.cand_cap = cand_cap;
+    const uint32_t threads = (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", 1024)));
+    const size_t lds = (size_t)F.bitmap_words * 4;
+    const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
+    const uint32_t grid = ctx->n_cu * wg_per_cu;
+    const uint64_t n_waves = (uint64_t)grid * (threads / 64);
+    const uint64_t n_chunks = (P.hi - (P.lo & ~1023ull) + 1023) / 1024;
+    uint64_t span = n_chunks / (n_waves * 8) + 1;
+    span = std::min<uint64_t>(std::max<uint64_t>(span, 1), 4096);
+    const int fs = env_int("SPM_HIP_FILTER_SPAN", 0);
+    if (fs > 0)
+        span = (uint64_t)fs;
+    P.span_chunks = (uint32_t)span;
+
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
+#define LAUNCH_FILTER(S)                                                                                               \
+    hipFuncSetAttribute((const void *)seed_filter_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    hipLaunchKernelGGL((seed_filter_kernel<S>), dim3(grid), dim3(threads), lds, ctx->stream, P)
+    switch (F.stride) {
+    case 16: LAUNCH_FILTER(16); break;
+    case 8: LAUNCH_FILTER(8); break;
+    case 4: LAUNCH_FILTER(4); break;
+    case 2: LAUNCH_FILTER(2); break;
+    default: LAUNCH_FILTER(1); break;
+    }
+#undef LAUNCH_FILTER
+    SPM_HIP_CHECK(ctx, hipGetLastError());
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
+    H->stats.main_launches++;
+
+    verify_params V{};
+    V.text = A.text->d;
+    V.ctx_begin = A.ctx_begin;
+    V.scan_begin = A.begin;
+    V.scan_end = A.end;
+    V.pos_offset = A.opts.pos_offset;
+    V.cand = d_cand;
+    V.counters = H->d_count;
+    V.cand_cap = cand_cap;
+    V.peq64 = ps->d_peq64;
+    V.m = ps->d_m;
+    V.k = ps->d_k;
+    V.report_begin = ps->is_myers() ? 0 : 1;
+    V.seen = d_seen;
+    V.seen_mask = (uint32_t)(seen_slots - 1);
+    V.hits = H->d_hits;
+    V.hit_counter = H->d_count;
+    V.hit_cap = H->cap;
+    V.overflow = H->d_count + 2;
+    launch_verify(ps->NB64, V, dim3(ctx->n_cu * 2), ctx->stream);
+    SPM_HIP_CHECK(ctx, hipGetLastError());
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
+    H->cand_cap = cand_cap;
+    return SPM_OK;
+}
+
+} // namespace
+
+extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end,
+                            const spm_patterns *patterns, const spm_scan_opts *opts_in, const void *state_in,
+                            void *state_out, spm_hits **out)
+{
+    if (!ctx || !text || !patterns || !out || begin > end || end > text->n) {
+        SPM_SET_ERR(ctx, "spm_hip_scan: invalid argument");
+        return SPM_E_INVALID;
+    }
+    if (patterns->sigma != text->sigma) {
+        SPM_SET_ERR(ctx, "spm_hip_scan: text sigma %u != pattern sigma %u", text->sigma, patterns->sigma);
+        return SPM_E_INVALID;
+    }
+    spm_scan_opts opts{};
+    if (opts_in)
+        opts = *opts_in;
+    SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+    std::unique_ptr<spm_hits, void (*)(spm_hits *)> H(new spm_hits, spm_hip_hits_destroy);
+    H->ctx = ctx;
+    H->cap = opts.max_hits ? opts.max_hits : (1ull << 20);
+    SPM_HIP_CHECK(ctx, hipMalloc(&H->d_hits, std::max<uint64_t>(H->cap, 1) * sizeof(spm_hit)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 8 * sizeof(unsigned long long)));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    for (int i = 0; i < 4; ++i)
+        SPM_HIP_CHECK(ctx, hipEventCreate(&H->ev[i]));
+
+    scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
+
+    const bool has_state = state_in != nullptr;
+    const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && patterns->fidx.ok);
+    if (opts.engine == SPM_ENGINE_FILTER && (!patterns->fidx.ok || has_state)) {
+        SPM_SET_ERR(ctx, "spm_hip_scan: the seed filter does not apply to this needle set / a restored state");
+        return SPM_E_UNSUPPORTED;
+    }
+    bool use_filter = want_filter && !has_state && patterns->n > 0 && end > begin;
+
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[0], ctx->stream));
+    H->timed = true;
+    if (patterns->n == 0 || end == begin) {
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
+        H->stats.engine_used = SPM_ENGINE_BRUTE;
+        if (state_in && state_out && state_out != state_in)
+            memcpy(state_out, state_in, spm_hip_patterns_state_stride(patterns) * patterns->n);
+        *out = H.release();
+        return SPM_OK;
+    }
+
+    if (use_filter) {
+        H->stats.engine_used = SPM_ENGINE_FILTER;
+        int rc = run_filter(A);
+        if (rc != SPM_OK)
+            return rc;
+        // overflow check needs the counters: one small D2H copy; on overflow re-run brute force
+        unsigned long long c[4] = {0, 0, 0, 0};
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        H->stats.n_candidates = c[1];
+        if (c[1] > H->cand_cap || c[2] != 0) {
+            H->stats.fell_back = 1;
+            use_filter = false;
+            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        } else {
+            H->n = c[0];
+            H->counted = true;
+        }
+    }
+    if (!use_filter) {
+        H->stats.engine_used = SPM_ENGINE_BRUTE;
+        // state plumbing
+        uint32_t *d_in = nullptr, *d_out = nullptr;
+        std::vector<uint32_t> h_in;
+        const uint32_t rows = patterns->is_myers() ? 2 * patterns->NW + 1 : patterns->NW;
+        const size_t st_words = (size_t)patterns->n_groups * rows * 64;
+        if (has_state || state_out) {
+            SPM_HIP_CHECK(ctx, hipMalloc(&d_in, st_words * 4 * 2));
+            d_out = d_in + st_words;
+        }
+        if (has_state) {
+            state_to_internal(patterns, state_in, h_in);
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in.data(), st_words * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
+        const uint64_t range = end - begin;
+        // a scan that must hand back an exact state and fits one tile does both in one pass
+        const bool one_pass_state = state_out && (range <= (1u << 16) || patterns->algo == SPM_ALGO_MYERS_PREFIX);
+        int rc = run_brute(A, begin, end, A.ctx_begin, has_state ? d_in : nullptr, one_pass_state ? d_out : nullptr,
+                           true, one_pass_state);
+        if (rc != SPM_OK) {
+            hipFree(d_in);
+            return rc;
+        }
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
+        if (state_out && !one_pass_state) {
+            // State after the last symbol: sequentially exact from a cold start 2*max|P| symbols earlier
+            // (every DP cell D[i][j] <= i has an optimal alignment spanning <= 2i symbols).
+            const uint64_t tail = std::min<uint64_t>(range, 2ull * patterns->max_m + 4);
+            const uint64_t tb = end - tail;
+            const bool from_state = has_state && tb == begin;
+            rc = run_brute(A, tb, end, tb, from_state ? d_in : nullptr, d_out, false, true);
+            if (rc != SPM_OK) {
+                hipFree(d_in);
+                return rc;
+            }
+        }
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
+        if (state_out) {
+            std::vector<uint32_t> h_out(st_words);
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(h_out.data(), d_out, st_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+            SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            state_from_internal(patterns, h_out, state_out);
+        }
+        if (d_in) {
+            SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(d_in);
+        }
+    }
+    *out = H.release();
+    return SPM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// hits
+// ----------------------------------------------------------------------------------------------------
+static int hits_count(spm_hits *h)
+{
+    spm_ctx *ctx = h->ctx;
+    if (!h->counted) {
+        unsigned long long c[4] = {0, 0, 0, 0};
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        h->n = c[0];
+        if (h->stats.engine_used == SPM_ENGINE_FILTER)
+            h->stats.n_candidates = c[1];
+        h->counted = true;
+    }
+    if (h->n > h->cap) {
+        SPM_SET_ERR(ctx, "scan produced %llu hits but the buffer holds %llu; raise spm_scan_opts.max_hits",
+                    (unsigned long long)h->n, (unsigned long long)h->cap);
+        return SPM_E_OVERFLOW;
+    }
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_hits_view(spm_hits *h, const spm_hit **records, uint64_t *n)
+{
+    if (!h || !records || !n)
+        return SPM_E_INVALID;
+    int rc = hits_count(h);
+    if (rc != SPM_OK)
+        return rc;
+    if (!h->sorted_host) {
+        h->host.resize(h->n);
+        if (h->n) {
+            SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(h->host.data(), h->d_hits, h->n * sizeof(spm_hit),
+                                                 hipMemcpyDeviceToHost, h->ctx->stream));
+            SPM_HIP_CHECK(h->ctx, hipStreamSynchronize(h->ctx->stream));
+        }
+        std::sort(h->host.begin(), h->host.end(), [](const spm_hit &a, const spm_hit &b) {
+            return a.pattern != b.pattern ? a.pattern < b.pattern : a.pos < b.pos;
+        });
+        h->sorted_host = true;
+    }
+    *records = h->host.data();
+    *n = h->n;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_hits_device(spm_hits *h, const void **device_records, uint64_t *n)
+{
+    if (!h || !device_records || !n)
+        return SPM_E_INVALID;
+    int rc = hits_count(h);
+    if (rc != SPM_OK)
+        return rc;
+    *device_records = h->d_hits;
+    *n = h->n;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_hits_stats(const spm_hits *hc, spm_scan_stats *out)
+{
+    if (!hc || !out)
+        return SPM_E_INVALID;
+    spm_hits *h = const_cast<spm_hits *>(hc);
+    int rc = hits_count(h);
+    if (rc != SPM_OK && rc != SPM_E_OVERFLOW)
+        return rc;
+    if (h->timed) {
+        SPM_HIP_CHECK(h->ctx, hipEventSynchronize(h->ev[3]));
+        hipEventElapsedTime(&h->stats.ms_total, h->ev[0], h->ev[3]);
+        hipEventElapsedTime(&h->stats.ms_main, h->ev[1], h->ev[2]);
+        hipEventElapsedTime(&h->stats.ms_verify, h->ev[2], h->ev[3]);
+    }
+    h->stats.n_hits = h->n;
+    *out = h->stats;
+    return SPM_OK;
+}
+
+extern "C" uint64_t spm_hip_hits_checksum(spm_hits *h)
+{
+    const spm_hit *r = nullptr;
+    uint64_t n = 0;
+    if (spm_hip_hits_view(h, &r, &n) != SPM_OK)
+        return 0;
+    uint64_t s = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        s += mix64(r[i].pos ^ ((uint64_t)r[i].pattern << 40) ^ ((uint64_t)(uint32_t)r[i].score << 58));
+    return s;
+}
+
+extern "C" void spm_hip_hits_destroy(spm_hits *h)
+{
+    if (!h)
+        return;
+    if (h->ctx)
+        hipStreamSynchronize(h->ctx->stream);
+    hipFree(h->d_hits);
+    hipFree(h->d_count);
+    for (int i = 0; i < 6; ++i)
+        if (h->ev[i])
+            hipEventDestroy(h->ev[i]);
+    delete h;
+}
+
+extern "C" uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p,
+                                          uint32_t L, uint32_t kmax, uint8_t *out)
+{
+    return synth_pattern(seed_text, seed_pat, n_total, p, L, kmax, out);
+}
+
+extern "C" uint64_t spm_hip_mix64(uint64_t z) { return mix64(z); }
+
+extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.1 (gfx950)"; }

@@ -1,0 +1,211 @@
+"""Thin object layer over the C ABI, used by tests, bench.py and the multi-GPU driver.
+
+Names follow the reference's domain: a *haystack* (Text) is scanned for a set of *needles* (PatternSet); a scan
+returns hit records (pos, pattern, score) -- what the reference's callback reads off the seqan2::Finder
+(/root/reference/libspm/libspm/matcher/seqan_pattern_base.hpp:40-52).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+HIT_DTYPE = np.dtype([("pos", "<u8"), ("pattern", "<u4"), ("score", "<i4")])
+
+
+def _check(rc, ctx_handle):
+    if rc != 0:
+        msg = capi.lib().spm_hip_last_error(ctx_handle)
+        raise capi.SpmError(f"libspm_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        rc = capi.lib().spm_hip_init(device, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc != 0:
+            msg = capi.lib().spm_hip_last_error(None)
+            raise capi.SpmError(f"spm_hip_init failed ({rc}): {msg.decode() if msg else ''}")
+        self.device = device
+
+    def synchronize(self):
+        _check(capi.lib().spm_hip_synchronize(self._h), self._h)
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- haystacks ----
+    def upload(self, ranks, sigma: int = 4) -> "Text":
+        a = np.ascontiguousarray(ranks, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_text_upload(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size, sigma,
+                                              C.byref(h)), self._h)
+        return Text(self, h, sigma)
+
+    def wrap(self, device_ptr: int, n: int, sigma: int = 4, keepalive=None) -> "Text":
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_text_wrap(self._h, C.c_void_p(device_ptr), n, sigma, C.byref(h)), self._h)
+        t = Text(self, h, sigma)
+        t._keepalive = keepalive
+        return t
+
+    def generate(self, seed: int, global_begin: int, n: int) -> "Text":
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_text_generate(self._h, seed, global_begin, n, C.byref(h)), self._h)
+        return Text(self, h, 4)
+
+    # ---- needles ----
+    def patterns(self, algo: int, needles, k=0, sigma: int = 4) -> "PatternSet":
+        needles = [np.ascontiguousarray(p, dtype=np.uint8) for p in needles]
+        offs = np.zeros(len(needles) + 1, dtype=np.uint32)
+        if needles:
+            offs[1:] = np.cumsum([len(p) for p in needles])
+        cat = np.concatenate(needles) if needles and offs[-1] else np.zeros(1, np.uint8)
+        if np.isscalar(k):
+            ks = np.full(max(1, len(needles)), k, dtype=np.uint16)
+        else:
+            ks = np.ascontiguousarray(k, dtype=np.uint16)
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_patterns_create(self._h, algo, cat.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  offs.ctypes.data_as(C.POINTER(C.c_uint32)), len(needles),
+                                                  ks.ctypes.data_as(C.POINTER(C.c_uint16)), sigma, C.byref(h)),
+               self._h)
+        return PatternSet(self, h, algo, len(needles))
+
+
+class Text:
+    def __init__(self, ctx, h, sigma):
+        self.ctx, self._h, self.sigma = ctx, h, sigma
+        self._keepalive = None
+
+    def __len__(self):
+        return int(capi.lib().spm_hip_text_length(self._h))
+
+    @property
+    def device_ptr(self) -> int:
+        return int(capi.lib().spm_hip_text_device_ptr(self._h) or 0)
+
+    def download(self, begin: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint8)
+        _check(capi.lib().spm_hip_text_download(self.ctx._h, self._h, begin, n,
+                                                out.ctypes.data_as(C.POINTER(C.c_uint8))), self.ctx._h)
+        return out
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_text_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PatternSet:
+    def __init__(self, ctx, h, algo, n):
+        self.ctx, self._h, self.algo, self.n = ctx, h, algo, n
+
+    def window_size(self, p: int = 0) -> int:
+        return int(capi.lib().spm_hip_patterns_window_size(self._h, p))
+
+    @property
+    def filterable(self) -> bool:
+        return bool(capi.lib().spm_hip_patterns_filterable(self._h))
+
+    def state_stride(self) -> int:
+        return int(capi.lib().spm_hip_patterns_state_stride(self._h))
+
+    def initial_state(self) -> np.ndarray:
+        st = np.zeros(self.state_stride() * max(1, self.n), dtype=np.uint8)
+        _check(capi.lib().spm_hip_patterns_state_init(self._h, st.ctypes.data), self.ctx._h)
+        return st
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_patterns_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Hits:
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    def view(self) -> np.ndarray:
+        """Hits sorted by (pattern, pos): per pattern, the order the reference's callback fires in."""
+        rec = C.POINTER(capi.Hit)()
+        n = C.c_uint64()
+        _check(capi.lib().spm_hip_hits_view(self._h, C.byref(rec), C.byref(n)), self.ctx._h)
+        if n.value == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        buf = (capi.Hit * n.value).from_address(C.addressof(rec.contents))
+        return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+
+    def device(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        _check(capi.lib().spm_hip_hits_device(self._h, C.byref(p), C.byref(n)), self.ctx._h)
+        return int(p.value or 0), int(n.value)
+
+    def stats(self) -> capi.ScanStats:
+        s = capi.ScanStats()
+        _check(capi.lib().spm_hip_hits_stats(self._h, C.byref(s)), self.ctx._h)
+        return s
+
+    def checksum(self) -> int:
+        return int(capi.lib().spm_hip_hits_checksum(self._h))
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_hits_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scan(ctx: Context, text: Text, pats: PatternSet, begin: int = 0, end: int | None = None, *,
+         engine: int = capi.ENGINE_AUTO, left_context: bool = False, pos_offset: int = 0, max_hits: int = 0,
+         state_in: np.ndarray | None = None, want_state: bool = False):
+    """One scan of text[begin:end) -- seqan_pattern_base::operator() for a whole needle set.
+
+    Returns Hits, or (Hits, state_out) when want_state is set."""
+    end = len(text) if end is None else end
+    opts = capi.ScanOpts(engine=engine, left_context=1 if left_context else 0, pos_offset=pos_offset,
+                         max_hits=max_hits, sort=0, reserved=0)
+    h = C.c_void_p()
+    st_in = state_in.ctypes.data if state_in is not None else None
+    st_out = None
+    if want_state:
+        st_out = np.zeros(pats.state_stride() * max(1, pats.n), dtype=np.uint8)
+    _check(capi.lib().spm_hip_scan(ctx._h, text._h, begin, end, pats._h, C.byref(opts), st_in,
+                                   st_out.ctypes.data if st_out is not None else None, C.byref(h)), ctx._h)
+    hits = Hits(ctx, h)
+    return (hits, st_out) if want_state else hits
+
+
+def synth_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, kmax: int):
+    out = np.empty(L, dtype=np.uint8)
+    o = capi.lib().spm_hip_synth_pattern(seed_text, seed_pat, n_total, p, L, kmax,
+                                         out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out, int(o)

@@ -1,0 +1,221 @@
+"""GPU parity tests: the HIP engines, called through the C ABI, against the CPU oracle (bit-exact)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _hits_list(h):
+    return [(int(a), int(b), int(c)) for a, b, c in zip(h["pattern"], h["pos"], h["score"])]
+
+
+def _oracle_multi(O, algo, text, needles, ks):
+    """Oracle hits for a needle set, (pattern, pos, score) sorted -- one pass per needle like the reference."""
+    out = []
+    for p, nd in enumerate(needles):
+        if len(nd) == 0:
+            continue
+        if algo == "myers":
+            r = O.myers(text, nd, ks[p])
+            out += [(p, int(a), int(s)) for a, s in zip(r["pos"], r["score"])]
+        else:
+            r = O.shiftor(text, nd)
+            out += [(p, int(a), 0) for a in r]
+    return sorted(out)
+
+
+def test_reference_golden_vectors(spm, ctx, oracle):
+    """Every known-answer row the reference's tests hold for this path (tests/golden/reference_vectors.json)."""
+    G = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+    H = oracle.encode(G["haystack"])
+    P = oracle.encode(G["needle"])
+    text = ctx.upload(H)
+    for case in G["cases"]:
+        algo = {"horspool": spm.ALGO_HORSPOOL, "shiftor": spm.ALGO_SHIFTOR}.get(case["matcher"], spm.ALGO_MYERS)
+        ps = ctx.patterns(algo, [P], k=case["k"])
+        assert ps.window_size(0) == case["window_size"]
+        for engine in (spm.ENGINE_BRUTE, spm.ENGINE_AUTO):
+            if "chunk_size" in case:
+                # restorable matcher: restore(state) before / capture() after each chunk
+                # (test/api/libspm/matcher/myers_matcher_restorable_test.cpp:55-74)
+                state = ps.initial_state()
+                got = []
+                cs = case["chunk_size"]
+                for off in range(0, len(H), cs):
+                    chunk = ctx.upload(H[off:off + cs])
+                    hits, state = spm.scan(ctx, chunk, ps, state_in=state, want_state=True, pos_offset=off)
+                    v = hits.view()
+                    got += list(zip(v["pos"].tolist(), v["score"].tolist()))
+            else:
+                v = spm.scan(ctx, text, ps, engine=engine).view()
+                got = list(zip(v["pos"].tolist(), v["score"].tolist()))
+            assert [g[0] for g in got] == case["expected"], (case["name"], engine)
+            if "scores" in case:
+                assert [g[1] for g in got] == case["scores"], (case["name"], engine)
+
+
+@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 300, 1024])
+@pytest.mark.parametrize("k", [0, 1, 3])
+def test_myers_brute_block_borders(spm, ctx, oracle, m, k):
+    """|P| around every word border, needles of mixed length in one set, planted occurrences with edits."""
+    if k >= m:
+        pytest.skip("k >= |P|")
+    rng = np.random.default_rng(1000 * m + k)
+    n = 20000
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles, ks = [], []
+    for i in range(70):  # > 64 needles: two lane groups
+        mm = m if i % 3 else max(1, m - (i % 7))
+        nd = rng.integers(0, 4, mm, dtype=np.uint8)
+        at = int(rng.integers(0, n - 2 * mm - 8))
+        occ = nd.copy()
+        if i % 4 == 1 and mm > 2:
+            occ = np.delete(occ, mm // 2)
+        elif i % 4 == 2 and mm > 2:
+            occ = np.insert(occ, mm // 3, (occ[mm // 3] + 1) & 3)
+        elif i % 4 == 3:
+            occ[mm // 2] = (occ[mm // 2] + 1) & 3
+        T[at:at + len(occ)] = occ
+        needles.append(nd)
+        ks.append(min(k, mm - 1) if mm > 1 else 0)
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=ks)
+    got = _hits_list(spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view())
+    want = _oracle_multi(oracle, "myers", T, needles, ks)
+    assert got == want
+
+
+@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 64, 65, 100, 129])
+def test_shiftor_brute(spm, ctx, oracle, m):
+    rng = np.random.default_rng(77 + m)
+    n = 30000
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles = []
+    for i in range(66):
+        nd = rng.integers(0, 4, m, dtype=np.uint8)
+        at = int(rng.integers(0, n - 3 * m - 4))
+        T[at:at + m] = nd
+        if i % 5 == 0 and m > 2:  # overlapping occurrences: periodic needle
+            nd[:] = nd[0]
+            T[at:at + 2 * m] = nd[0]
+        needles.append(nd)
+    text = ctx.upload(T)
+    for algo in (spm.ALGO_SHIFTOR, spm.ALGO_HORSPOOL):
+        ps = ctx.patterns(algo, needles)
+        got = _hits_list(spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view())
+        want = _oracle_multi(oracle, "shiftor", T, needles, None)
+        assert got == want
+
+
+def _planted_config(spm, oracle, n_total, n_pat, L, kmax, seed_text=0x5EED0001, seed_pat=0x5EED0002):
+    needles = [spm.synth_pattern(seed_text, seed_pat, n_total, p, L, kmax)[0] for p in range(n_pat)]
+    return needles
+
+
+@pytest.mark.parametrize("cfg", [("myers", 100, 3, 256), ("myers", 150, 3, 100), ("shiftor", 32, 0, 256),
+                                 ("myers", 64, 1, 64), ("myers", 1024, 10, 8)])
+def test_filter_engine_equals_brute_and_oracle(spm, ctx, oracle, cfg):
+    """Seed filter + verification must return exactly the brute-force hit set (and the oracle's)."""
+    algo, L, kmax, n_pat = cfg
+    n = 1 << 22
+    text = ctx.generate(0x5EED0001, 0, n)
+    needles = _planted_config(spm, oracle, n, n_pat, L, kmax)
+    a = spm.ALGO_MYERS if algo == "myers" else spm.ALGO_SHIFTOR
+    ps = ctx.patterns(a, needles, k=kmax)
+    assert ps.filterable
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE)
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
+    assert hf.stats().engine_used == spm.ENGINE_FILTER and hf.stats().fell_back == 0
+    vb, vf = hb.view(), hf.view()
+    assert len(vb) >= n_pat  # every needle has a planted occurrence
+    assert np.array_equal(vb, vf)
+    assert hb.checksum() == hf.checksum()
+    # oracle on a subset of needles over the whole text
+    T = text.download(0, n)
+    assert np.array_equal(T[:4096], oracle.text(0x5EED0001, 0, 4096))
+    sub = list(range(0, n_pat, max(1, n_pat // 8)))
+    want = _oracle_multi(oracle, algo, T, [needles[i] for i in sub], [kmax] * len(sub))
+    got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(vf) if p in sub]
+    assert sorted(got) == want
+
+
+def test_left_context_sharding_equals_whole_scan(spm, ctx, oracle):
+    """Shard rule of SURVEY 8(e): shards with left context reproduce the whole-text hit list exactly."""
+    n = 1 << 20
+    text = ctx.generate(0x5EED0001, 0, n)
+    needles = _planted_config(spm, oracle, n, 128, 100, 3)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+    for engine in (spm.ENGINE_BRUTE, spm.ENGINE_FILTER):
+        whole = spm.scan(ctx, text, ps, engine=engine).view()
+        parts = []
+        cuts = [0, 1000, 333333, 700001, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            parts.append(spm.scan(ctx, text, ps, a, b, engine=engine, left_context=True).view())
+        merged = np.sort(np.concatenate(parts), order=["pattern", "pos"])
+        assert np.array_equal(merged, whole)
+
+
+def test_restorable_state_chunks_random(spm, ctx, oracle):
+    """capture()/restore() across ragged chunks == one sequential scan (Myers |P|=100 and Shift-Or |P|=40)."""
+    rng = np.random.default_rng(5)
+    n = 5000
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles = [rng.integers(0, 4, 100, dtype=np.uint8) for _ in range(3)]
+    for i, nd in enumerate(needles):
+        T[700 * (i + 1):700 * (i + 1) + 100] = nd
+    cuts = [0, 13, 14, 700, 790, 1405, 3000, n]
+    for algo, k in ((spm.ALGO_MYERS, 3), (spm.ALGO_SHIFTOR, 0)):
+        nds = needles if algo == spm.ALGO_MYERS else [nd[:40] for nd in needles]
+        ps = ctx.patterns(algo, nds, k=k)
+        whole = spm.scan(ctx, ctx.upload(T), ps, engine=spm.ENGINE_BRUTE).view()
+        state = ps.initial_state()
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            hits, state = spm.scan(ctx, ctx.upload(T[a:b]), ps, state_in=state, want_state=True, pos_offset=a)
+            parts.append(hits.view())
+        merged = np.sort(np.concatenate(parts), order=["pattern", "pos"])
+        assert np.array_equal(merged, whole)
+        assert len(whole) >= 3
+
+
+def test_edge_cases(spm, ctx, oracle):
+    T = oracle.encode("ACGTACGTAC")
+    text = ctx.upload(T)
+    # empty needle set, empty needle, needle longer than the text, empty range
+    assert len(spm.scan(ctx, text, ctx.patterns(spm.ALGO_MYERS, [], k=0)).view()) == 0
+    ps = ctx.patterns(spm.ALGO_MYERS, [np.zeros(0, np.uint8), oracle.encode("ACGTACGTACGTACGT")], k=[0, 1])
+    assert ps.window_size(0) == 0 and ps.window_size(1) == 17
+    assert len(spm.scan(ctx, text, ps).view()) == 0
+    ps = ctx.patterns(spm.ALGO_SHIFTOR, [oracle.encode("AC")])
+    assert spm.scan(ctx, text, ps).view()["pos"].tolist() == [0, 4, 8]
+    assert len(spm.scan(ctx, text, ps, 3, 3).view()) == 0
+    # sub-range without left context is a haystack of its own
+    assert spm.scan(ctx, text, ps, 1, 10).view()["pos"].tolist() == [4, 8]
+    # dna5 haystack (ranks A0 C1 G2 N3 T4) through the brute engine
+    T5 = oracle.encode("ACGNTACGNTAACGT", 5)
+    P5 = oracle.encode("ACGNT", 5)
+    ps5 = ctx.patterns(spm.ALGO_MYERS, [P5], k=1, sigma=5)
+    got = spm.scan(ctx, ctx.upload(T5, sigma=5), ps5).view()
+    want = oracle.myers(T5, P5, 1, sigma=5)
+    assert got["pos"].tolist() == want["pos"].tolist() and got["score"].tolist() == want["score"].tolist()
+
+
+def test_prefix_matcher(spm, ctx, oracle):
+    """restorable_myers_prefix_matcher: global start, scan bounded to |P|+k+1 symbols
+    (matcher/myers_prefix_matcher_restorable.hpp:47-61).  PARITY UNPINNED by the reference; pinned on Sellers."""
+    rng = np.random.default_rng(9)
+    for m, k in ((5, 1), (40, 3), (100, 3), (130, 5)):
+        P = rng.integers(0, 4, m, dtype=np.uint8)
+        T = np.concatenate([np.delete(P, m // 2), rng.integers(0, 4, 50, dtype=np.uint8)])
+        bound = min(len(T), m + k + 1)
+        ps = ctx.patterns(spm.ALGO_MYERS_PREFIX, [P], k=k)
+        got = spm.scan(ctx, ctx.upload(T), ps, 0, bound).view()
+        want = oracle.sellers(T[:bound], P, k, mode=oracle.PREFIX)
+        assert got["pos"].tolist() == want["pos"].tolist()
+        assert got["score"].tolist() == want["score"].tolist()
+        assert len(want) >= 1
