@@ -143,6 +143,9 @@ int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t en
 int spm_hip_hits_view(spm_hits *hits, const spm_hit **records, uint64_t *n);
 /* Device view (unsorted unless opts.sort): pointer to n spm_hit records in HBM, for an RCCL gatherv. */
 int spm_hip_hits_device(spm_hits *hits, const void **device_records, uint64_t *n);
+/* Copy the first min(n, cap) records into a caller-owned device buffer (e.g. a torch tensor that an RCCL
+ * send/recv will read), asynchronously on the context's stream.  *n receives the number of hits. */
+int spm_hip_hits_copy_device(spm_hits *hits, void *device_dst, uint64_t cap, uint64_t *n);
 int spm_hip_hits_stats(const spm_hits *hits, spm_scan_stats *out);
 /* order-independent checksum: sum over hits of mix64(pos ^ pattern<<40 ^ score<<58), SURVEY.md 8(d) */
 uint64_t spm_hip_hits_checksum(spm_hits *hits);

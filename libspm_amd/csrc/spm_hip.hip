@@ -1031,6 +1031,21 @@ extern "C" int spm_hip_hits_device(spm_hits *h, const void **device_records, uin
     return SPM_OK;
 }
 
+extern "C" int spm_hip_hits_copy_device(spm_hits *h, void *device_dst, uint64_t cap, uint64_t *n)
+{
+    if (!h || !n || (cap && !device_dst))
+        return SPM_E_INVALID;
+    int rc = hits_count(h);
+    if (rc != SPM_OK)
+        return rc;
+    *n = h->n;
+    const uint64_t c = std::min(h->n, cap);
+    if (c)
+        SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(device_dst, h->d_hits, c * sizeof(spm_hit), hipMemcpyDeviceToDevice,
+                                             h->ctx->stream));
+    return SPM_OK;
+}
+
 extern "C" int spm_hip_hits_stats(const spm_hits *hc, spm_scan_stats *out)
 {
     if (!hc || !out)

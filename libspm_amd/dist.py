@@ -1,0 +1,56 @@
+"""Multi-GPU driver pieces: text sharding and the gatherv of hit records.
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm ("gloo" in the CPU tests).  The
+path shards by text position: rank g owns the hits whose last symbol lies in its range and reads window_size-1
+symbols of left context, so no data-path collective is needed during the scan.  The only exchange is one gatherv of
+16-byte hit records to rank 0 at the end: an all_gather of the per-rank counts, then grouped send/recv
+(ncclGroupStart .. ncclSend/ncclRecv .. ncclGroupEnd under torch's batch_isend_irecv) -- RCCL has no native gatherv.
+Hit traffic is tiny (<= a few MB), so ring-vs-tree and the 7 x ~153 GB/s xGMI links are irrelevant to throughput; the
+collective only has to be correct.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int, align: int = 1024):
+    """Contiguous shard [lo, hi) of rank `rank`; boundaries aligned so device loads stay 16-byte aligned."""
+    per = (n_total + world - 1) // world
+    per = (per + align - 1) // align * align
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+def gatherv_hits(local: torch.Tensor, dst: int = 0, group=None):
+    """local: int64 tensor [n, 2] (16-byte hit records viewed as two int64).  Returns on `dst` the concatenation
+    of every rank's records in rank order (= ascending shard order), elsewhere None."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    local = local.contiguous()
+    if rank == dst:
+        out = torch.empty((sum(counts), 2), dtype=torch.int64, device=local.device)
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        ops = []
+        for r in range(world):
+            if r == dst:
+                out[offs[r]:offs[r + 1]].copy_(local)
+            elif counts[r] > 0:
+                ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+    if counts[rank] > 0:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)]):
+            req.wait()
+    return None

@@ -164,6 +164,12 @@ class Hits:
         _check(capi.lib().spm_hip_hits_device(self._h, C.byref(p), C.byref(n)), self.ctx._h)
         return int(p.value or 0), int(n.value)
 
+    def copy_to(self, device_ptr: int, cap: int) -> int:
+        """Async D2D copy of the hit records into a caller-owned device buffer; returns the hit count."""
+        n = C.c_uint64()
+        _check(capi.lib().spm_hip_hits_copy_device(self._h, C.c_void_p(device_ptr), cap, C.byref(n)), self.ctx._h)
+        return int(n.value)
+
     def stats(self) -> capi.ScanStats:
         s = capi.ScanStats()
         _check(capi.lib().spm_hip_hits_stats(self._h, C.byref(s)), self.ctx._h)

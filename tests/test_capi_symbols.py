@@ -1,0 +1,55 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/spm_hip.h declares; calls that need a
+device fail loudly with an error code and message (no silent fallback)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "spm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(spm_hip_\w+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported(spm):
+    names = _declared()
+    assert len(names) >= 25
+    L = ctypes.CDLL(spm.capi.SO_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/spm_hip.h but not exported by libspm_hip.so"
+    assert sorted(spm.capi.EXPORTS) == names, "libspm_amd/capi.py binding list out of sync with the header"
+
+
+def test_version_and_struct_layout(spm):
+    assert b"gfx950" in spm.capi.lib().spm_hip_version()
+    assert ctypes.sizeof(spm.capi.Hit) == 16
+    assert spm.HIT_DTYPE.itemsize == 16
+    assert ctypes.sizeof(spm.capi.ScanOpts) == 32
+    assert ctypes.sizeof(spm.capi.ScanStats) == 48
+
+
+def test_no_device_fails_loudly(spm):
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        spm.Context(0)
+    except spm.SpmError as e:
+        assert "spm_hip_init failed" in str(e)
+    else:
+        raise AssertionError("Context(0) succeeded without a GPU")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under libspm_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("libspm_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    src = open(os.path.join(d, f), errors="ignore").read()
+                    if re.search(r"(import\s+oracle|from\s+oracle|spm_oracle\.h|libspm_oracle)", src):
+                        bad.append(os.path.join(d, f))
+    assert not bad, bad

@@ -1,0 +1,61 @@
+"""CPU, world_size 2, gloo: the N>1 path -- text sharding and the gatherv of hit records to rank 0."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, counts, q):
+    sys.path.insert(0, ROOT)
+    from libspm_amd import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = counts[rank]
+        local = torch.empty((n, 2), dtype=torch.int64)
+        local[:, 0] = torch.arange(n) + 1000 * rank  # pos
+        local[:, 1] = rank                            # pattern|score word
+        out = sdist.gatherv_hits(local, dst=0)
+        if rank == 0:
+            q.put(out.numpy().copy())
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(3, 5), (0, 4), (7, 0), (0, 0)])
+def test_gatherv_hits_world2(counts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + sum(counts)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = np.concatenate([np.stack([np.arange(c) + 1000 * r, np.full(c, r)], 1) for r, c in enumerate(counts)]
+                          ).reshape(-1, 2)
+    assert np.array_equal(out, want)
+
+
+def test_shard_ranges_cover_text_once():
+    sys.path.insert(0, ROOT)
+    from libspm_amd import dist as sdist
+    for n_total in (1 << 20, (1 << 34) * 3 + 4096, 1000):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = sdist.shard_range(n_total, r, world)
+                assert lo == prev and lo % 1024 == 0 or lo == n_total
+                prev = hi
+            assert prev == n_total
