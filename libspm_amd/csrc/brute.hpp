@@ -96,13 +96,51 @@ __device__ __forceinline__ uint32_t load_text_dword(const uint8_t *text, uint64_
 
 // ---------------------------------------------------------------------------------------------------
 // Myers, NW 32-bit words per needle, one lane per needle.  PREFIX = MyersUkkonenGlobal carry-in.
+// Everything except the needle state is wave-uniform and is forced into SGPRs (readfirstlane), so the per-symbol
+// VALU work is the recurrence itself: per word 1 LDS read, ~9 VALU (v_bitop3 folds the 3-input boolean terms).
 // ---------------------------------------------------------------------------------------------------
+template <int NW, bool PREFIX>
+struct myers_lane
+{
+    uint32_t VP[NW], VN[NW];
+    uint32_t hp0[PREFIX ? NW : 1];
+    int32_t score;
+
+    __device__ __forceinline__ void step(const uint32_t *row /* &peq[c][0][lane] */)
+    {
+        uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            // 10 VALU per word: v_bitop3_b32 evaluates any 3-input boolean function (truth table with
+            // a = 0xF0, b = 0xCC, c = 0xAA), which folds every AND/OR/NOT pair of the recurrence.
+            const uint32_t eq = row[w * 64];
+            const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[w], VP[w], 0xA8); // (eq | VN) & VP
+            uint32_t cout;
+            const uint32_t sum = __builtin_addc(VP[w], t, carry, &cout);
+            carry = cout;
+            const uint32_t X = eq | VN[w];
+            const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, VP[w], X, 0xBE);    // (sum ^ VP) | X
+            const uint32_t HN = VP[w] & D0;
+            const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN[w], VP[w], D0, 0xF1); // VN | ~(VP | D0)
+            uint32_t Xs = alignbit(HP, hp_prev, 31);
+            if (PREFIX)
+                Xs |= hp0[w];
+            const uint32_t Ts = alignbit(HN, hn_prev, 31);
+            hp_prev = HP;
+            hn_prev = HN;
+            VN[w] = Xs & D0;
+            VP[w] = __builtin_amdgcn_bitop3_b32(Ts, Xs, D0, 0xF1);                   // Ts | ~(Xs | D0)
+        }
+        score += (int32_t)(hp_prev >> 31) - (int32_t)(hn_prev >> 31);
+    }
+};
+
 template <int NW, bool PREFIX>
 __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t waves_per_wg = blockDim.x >> 6;
     const uint32_t rows = P.sigma + 1;
     uint32_t *my_peq = lds + (size_t)wave_in_wg * rows * NW * 64; // this wave's table: [row][word][lane]
@@ -113,7 +151,7 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
 
     uint32_t loaded_group = 0xFFFFFFFFu;
     int32_t my_m = 0, my_k = -1;
-    uint32_t hp0[PREFIX ? NW : 1];
+    myers_lane<NW, PREFIX> L;
 
     for (uint64_t item = wave_id; item < n_items; item += n_waves) {
         const uint32_t group = (uint32_t)(item % P.n_groups);
@@ -127,12 +165,12 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
             if (PREFIX) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    hp0[w] = P.hp0[((size_t)group * NW + w) * 64 + lane];
+                    L.hp0[w] = P.hp0[((size_t)group * NW + w) * 64 + lane];
             }
             loaded_group = group;
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- tile geometry (all wave-uniform) ----
+        // ---- tile geometry (wave-uniform, SGPRs) ----
         const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
         uint64_t own_hi = own_lo + P.tile;
         if (own_hi > P.scan_end)
@@ -143,26 +181,26 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
             scan_lo = own_lo;
 
         // ---- initial state ----
-        uint32_t VP[NW], VN[NW];
-        int32_t score;
         if (resume) {
             const uint32_t *st = P.state_in + (size_t)group * (2 * NW + 1) * 64 + lane;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                VP[w] = st[w * 64];
-                VN[w] = st[(NW + w) * 64];
+                L.VP[w] = st[w * 64];
+                L.VN[w] = st[(NW + w) * 64];
             }
-            score = (int32_t)st[2 * NW * 64];
+            L.score = (int32_t)st[2 * NW * 64];
         } else {
             const int32_t off = NW * 32 - my_m;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const int32_t lo = off - w * 32; // bits >= lo are needle rows
-                VP[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
-                VN[w] = 0;
+                L.VP[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+                L.VN[w] = 0;
             }
-            score = my_m;
+            L.score = my_m;
         }
+        const uint32_t *lane_peq = my_peq + lane;
+        const uint32_t sigma = P.sigma;
 
         const uint64_t a0 = scan_lo & ~3ull;
         for (uint64_t cbase = a0; cbase < own_hi; cbase += 256) {
@@ -171,58 +209,63 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
             if (my_idx < own_hi)
                 v = load_text_dword(P.text, my_idx, P.text_alloc);
             const uint64_t rem = own_hi - cbase;
-            const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
-            const bool interior = (cbase >= scan_lo) && (rem >= 256);
-            for (uint32_t j = 0; j < n_dw; ++j) {
-                const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+            const bool full = (cbase >= scan_lo) && (rem >= 256);
+            if (full && cbase + 256 <= own_lo) {
+                // warm-up chunk: recurrence only
+                for (uint32_t j = 0; j < 64; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint64_t p = cbase + (uint64_t)j * 4 + s;
-                    if (!interior && (p < scan_lo || p >= own_hi))
-                        continue;
-                    uint32_t c = (w4 >> (8 * s)) & 0xFF;
-                    c = c < P.sigma ? c : P.sigma;
-                    const uint32_t *row = my_peq + (size_t)c * NW * 64 + lane;
-                    uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const uint32_t eq = row[w * 64];
-                        const uint32_t X = eq | VN[w];
-                        const uint32_t t = X & VP[w];
-                        uint32_t cout;
-                        const uint32_t sum = __builtin_addc(VP[w], t, carry, &cout);
-                        carry = cout;
-                        const uint32_t D0 = (sum ^ VP[w]) | X;
-                        const uint32_t HN = VP[w] & D0;
-                        const uint32_t HP = VN[w] | ~(VP[w] | D0);
-                        uint32_t Xs = alignbit(HP, hp_prev, 31);
-                        if (PREFIX)
-                            Xs |= hp0[w];
-                        const uint32_t Ts = alignbit(HN, hn_prev, 31);
-                        hp_prev = HP;
-                        hn_prev = HN;
-                        VN[w] = Xs & D0;
-                        VP[w] = Ts | ~(Xs | D0);
+                    for (int s = 0; s < 4; ++s) {
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        c = c < sigma ? c : sigma;
+                        L.step(lane_peq + (size_t)c * NW * 64);
                     }
-                    score += (int32_t)(hp_prev >> 31) - (int32_t)(hn_prev >> 31);
-                    const bool hit = score <= my_k;
-                    if (__ballot(hit) != 0 && p >= own_lo) {
-                        wave_append_hits(hit, p + 1 + P.pos_offset, group * 64 + lane, score, P.hits,
-                                         P.counters, P.hit_cap);
+                }
+            } else if (full && cbase >= own_lo) {
+                // owned interior chunk: recurrence + hit test, no range checks
+                for (uint32_t j = 0; j < 64; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        c = c < sigma ? c : sigma;
+                        L.step(lane_peq + (size_t)c * NW * 64);
+                        const bool hit = L.score <= my_k;
+                        if (__ballot(hit) != 0)
+                            wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 + P.pos_offset, group * 64 + lane,
+                                             L.score, P.hits, P.counters, P.hit_cap);
+                    }
+                }
+            } else {
+                // edge chunk: every symbol checked against [scan_lo, own_hi) and own_lo
+                const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
+                for (uint32_t j = 0; j < n_dw; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+                    for (int s = 0; s < 4; ++s) {
+                        const uint64_t p = cbase + (uint64_t)j * 4 + s;
+                        if (p < scan_lo || p >= own_hi)
+                            continue;
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        c = c < sigma ? c : sigma;
+                        L.step(lane_peq + (size_t)c * NW * 64);
+                        const bool hit = L.score <= my_k;
+                        if (p >= own_lo && __ballot(hit) != 0)
+                            wave_append_hits(hit, p + 1 + P.pos_offset, group * 64 + lane, L.score, P.hits,
+                                             P.counters, P.hit_cap);
                     }
                 }
             }
         }
         // The state after the last symbol is exact only when the recurrence ran over every symbol since the
-        // matcher was constructed -- the single-tile resume case (restorable matcher on a chunk).
-        if (P.state_out && tile == P.n_tiles - 1 && P.n_tiles == 1) {
+        // matcher was constructed or 2*|P| symbols from a cold start (host arranges a single-tile pass for it).
+        if (P.state_out && P.n_tiles == 1) {
             uint32_t *st = P.state_out + (size_t)group * (2 * NW + 1) * 64 + lane;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                st[w * 64] = VP[w];
-                st[(NW + w) * 64] = VN[w];
+                st[w * 64] = L.VP[w];
+                st[(NW + w) * 64] = L.VN[w];
             }
-            st[2 * NW * 64] = (uint32_t)score;
+            st[2 * NW * 64] = (uint32_t)L.score;
         }
     }
 }
@@ -240,7 +283,7 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t waves_per_wg = blockDim.x >> 6;
     const uint32_t rows = P.sigma + 1;
     uint32_t *my_mask = lds + (size_t)wave_in_wg * rows * NW * 64;
@@ -287,6 +330,19 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
             }
         }
         const bool active_lane = my_m > 0;
+        const uint32_t *lane_mask = my_mask + lane;
+        const uint32_t sigma = P.sigma;
+
+        auto step = [&](uint32_t c) {
+            const uint32_t *row = lane_mask + (size_t)c * NW * 64;
+            uint32_t prev = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t cur = R[w];
+                R[w] = alignbit(cur, prev, 31) | row[w * 64];
+                prev = cur;
+            }
+        };
 
         const uint64_t a0 = scan_lo & ~3ull;
         for (uint64_t cbase = a0; cbase < own_hi; cbase += 256) {
@@ -295,31 +351,45 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
             if (my_idx < own_hi)
                 v = load_text_dword(P.text, my_idx, P.text_alloc);
             const uint64_t rem = own_hi - cbase;
-            const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
-            const bool interior = (cbase >= scan_lo) && (rem >= 256);
-            for (uint32_t j = 0; j < n_dw; ++j) {
-                const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+            const bool full = (cbase >= scan_lo) && (rem >= 256);
+            if (full && cbase + 256 <= own_lo) {
+                for (uint32_t j = 0; j < 64; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint64_t p = cbase + (uint64_t)j * 4 + s;
-                    if (!interior && (p < scan_lo || p >= own_hi))
-                        continue;
-                    uint32_t c = (w4 >> (8 * s)) & 0xFF;
-                    c = c < P.sigma ? c : P.sigma;
-                    const uint32_t *row = my_mask + (size_t)c * NW * 64 + lane;
-                    uint32_t prev = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const uint32_t cur = R[w];
-                        R[w] = alignbit(cur, prev, 31) | row[w * 64];
-                        prev = cur;
+                    for (int s = 0; s < 4; ++s) {
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        step(c < sigma ? c : sigma);
                     }
-                    const bool hit = active_lane && ((int32_t)R[NW - 1] >= 0); // bit 31 clear
-                    if (__ballot(hit) != 0 && p >= own_lo) {
+                }
+            } else if (full && cbase >= own_lo) {
+                for (uint32_t j = 0; j < 64; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        step(c < sigma ? c : sigma);
+                        const bool hit = active_lane && ((int32_t)R[NW - 1] >= 0); // bit 31 clear
+                        if (__ballot(hit) != 0)
+                            wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 - (uint64_t)my_m + P.pos_offset,
+                                             group * 64 + lane, 0, P.hits, P.counters, P.hit_cap);
+                    }
+                }
+            } else {
+                const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
+                for (uint32_t j = 0; j < n_dw; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+                    for (int s = 0; s < 4; ++s) {
+                        const uint64_t p = cbase + (uint64_t)j * 4 + s;
+                        if (p < scan_lo || p >= own_hi)
+                            continue;
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        step(c < sigma ? c : sigma);
+                        const bool hit = active_lane && ((int32_t)R[NW - 1] >= 0);
                         // an occurrence that starts before the haystack's first symbol cannot exist; with a
                         // restored state it can start in an earlier chunk, whose coordinates the caller owns
-                        wave_append_hits(hit, p + 1 - (uint64_t)my_m + P.pos_offset, group * 64 + lane, 0,
-                                         P.hits, P.counters, P.hit_cap);
+                        if (p >= own_lo && __ballot(hit) != 0)
+                            wave_append_hits(hit, p + 1 - (uint64_t)my_m + P.pos_offset, group * 64 + lane, 0,
+                                             P.hits, P.counters, P.hit_cap);
                     }
                 }
             }

@@ -24,6 +24,14 @@ extern thread_local std::string g_init_error;
 
 } // namespace spm_hip
 
+struct hits_block // device buffers + events of one scan result, recycled through the context
+{
+    spm_hit *d_hits = nullptr;
+    unsigned long long *d_count = nullptr;
+    uint64_t cap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct spm_ctx
 {
     int device = 0;
@@ -34,7 +42,7 @@ struct spm_ctx
     // scratch reused across scans
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hits_block> pool;
 };
 
 struct spm_text

@@ -54,6 +54,7 @@ struct filter_params
     uint32_t bitmap_words;    // power of two, <= 32768 (128 KiB)
     uint32_t n_probes;        // Bloom probes per key
     uint32_t span_chunks;     // 1-KiB chunks per span
+    uint32_t hash_variant;
     const uint32_t *bitmap;   // [bitmap_words]
     const uint2 *ht;          // exact table: (key, val), val == kHtEmpty marks an empty slot
     uint32_t ht_mask;
@@ -62,12 +63,23 @@ struct filter_params
     uint64_t cand_cap;
 };
 
+template <int HV>
 __host__ __device__ inline uint32_t bloom_hash(uint32_t key, uint32_t i)
 {
-    // i-th probe index (before masking).  Multiplicative hashing, distinct odd constants.
-    const uint32_t c[4] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
-    uint32_t x = key ^ (key >> (15 + i));
-    return (x * c[i & 3]) >> 7; // 25 significant bits; callers mask to the bitmap size
+    // i-th probe index (before masking to the bitmap size).
+    if (HV == 0) {
+        // multiplicative hashing, distinct odd constants (v_mul_lo_u32 is quarter rate on CDNA)
+        const uint32_t c[4] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
+        uint32_t x = key ^ (key >> (15 + i));
+        return (x * c[i & 3]) >> 7;
+    } else {
+        // xor-shift + rotate: 3 full-rate VALU.  Index bits are GF(2)-linear in the key; on the text side the
+        // keys are (near) uniform 16-mers, so linearity costs nothing there.
+        const uint32_t sh[4] = {14, 11, 17, 9};
+        const uint32_t ro[4] = {0, 7, 13, 19};
+        const uint32_t x = key ^ (key >> sh[i & 3]);
+        return ro[i & 3] ? ((x >> ro[i & 3]) | (x << (32 - ro[i & 3]))) : x;
+    }
 }
 
 __host__ __device__ inline uint32_t ht_hash(uint32_t key)
@@ -102,7 +114,144 @@ __device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int S>
+// Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
+// (U KiB contiguous per wave) while the 16-byte loads of the next group are already in flight, so that each wave
+// keeps 2*U KiB outstanding -- the filter is bound by bytes in flight, not by issue (20-40 VGPRs, ~100 wave
+// instructions per KiB).
+template <bool NT>
+__device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
+{
+    if (NT) {
+        // streamed once: nontemporal keeps it from displacing the key table in L2 and measures +13 % on a pure
+        // 16 GiB read (tools/hbm_read_probe: 7.0 vs 6.2 TB/s)
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
+                          __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+// One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
+// gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
+template <int S, int UU, int HV>
+__device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
+                                             uint32_t &carry_in, uint32_t lane, const uint32_t *lds,
+                                             uint32_t idx_mask)
+{
+    constexpr int NWIN = 16 / S; // windows per lane per chunk
+    static_assert(UU * NWIN <= 32, "one mask bit per window of a group");
+    uint32_t w[UU], prev[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        w[u] = pack16(cur[u]);
+        prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+        if (lane == 0)
+            prev[u] = carry_in;
+        carry_in = __builtin_amdgcn_readlane(w[u], 63);
+    }
+    // windows d = S, 2S, .., 16 of chunk u: text start t = L_u - 16 + d, key = bits [2d, 2d+32) of (w:prev)
+    uint32_t pos_mask = 0;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+#pragma unroll
+        for (int i = 0; i < NWIN; ++i) {
+            const int d = S * (i + 1);
+            const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+            const uint32_t h = bloom_hash<HV>(key, 0) & idx_mask;
+            const uint32_t word = lds[h >> 5];
+            pos_mask |= __builtin_amdgcn_ubfe(word, h, 1) << (u * NWIN + i);
+        }
+    }
+    // cascade: further probes only for survivors
+    for (uint32_t pr = 1; pr < P.n_probes; ++pr) {
+        if (__ballot(pos_mask != 0) == 0)
+            break;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+#pragma unroll
+            for (int i = 0; i < NWIN; ++i) {
+                if (pos_mask & (1u << (u * NWIN + i))) {
+                    const int d = S * (i + 1);
+                    const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                    const uint32_t h = bloom_hash<HV>(key, pr) & idx_mask;
+                    const uint32_t word = lds[h >> 5];
+                    keep |= __builtin_amdgcn_ubfe(word, h, 1) << (u * NWIN + i);
+                }
+            }
+        }
+        pos_mask = keep;
+    }
+    // survivors: exact key table
+    while (__ballot(pos_mask != 0) != 0) {
+        bool emit = false;
+        uint64_t t = 0;
+        uint32_t val = 0;
+        uint32_t key = 0;
+        uint32_t slot = 0;
+        bool probing = false;
+        if (pos_mask != 0) {
+            const int bit = __ffs(pos_mask) - 1;
+            pos_mask &= pos_mask - 1;
+            const int u = bit / NWIN, i = bit % NWIN;
+            const int d = S * (i + 1);
+            uint32_t wu = w[0], pu = prev[0];
+#pragma unroll
+            for (int q = 1; q < UU; ++q)
+                if (u == q) {
+                    wu = w[q];
+                    pu = prev[q];
+                }
+            key = d == 16 ? wu : alignbit(wu, pu, (uint32_t)(2 * d) & 31u);
+            const int64_t ts = (int64_t)(gbase + (uint64_t)u * 1024 + (uint64_t)lane * 16) - 16 + d;
+            if (ts >= (int64_t)P.lo && (uint64_t)ts + kKeyH <= P.hi) {
+                t = (uint64_t)ts;
+                slot = ht_hash(key) & P.ht_mask;
+                probing = true;
+            }
+        }
+        while (__ballot(probing) != 0) {
+            emit = false;
+            if (probing) {
+                const uint2 e = P.ht[slot];
+                if (e.y == kHtEmpty) {
+                    probing = false;
+                } else {
+                    if (e.x == key) {
+                        emit = true;
+                        val = e.y;
+                    }
+                    slot = (slot + 1) & P.ht_mask;
+                }
+            }
+            const uint64_t m = __ballot(emit);
+            if (m != 0) {
+                const uint32_t n = __popcll(m);
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader)
+                    base = atomicAdd(&P.counters[1], (unsigned long long)n);
+                base = __shfl(base, leader);
+                if (emit) {
+                    const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
+                    if (idx < P.cand_cap) {
+                        candidate c;
+                        c.t = t;
+                        c.val = val;
+                        c.pad = 0;
+                        P.cand[idx] = c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
+// (U KiB contiguous per wave) while the unconditional 16-byte loads of the next group are already in flight, so
+// each wave keeps 2*U KiB outstanding.  Only groups that lie fully inside the text take this path; the ragged end
+// of the text goes through a guarded one-chunk loop (bytes past the end read as 0).
+template <int S, int U, bool NT, int HV>
 __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
@@ -113,16 +262,17 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t waves_per_wg = blockDim.x >> 6;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const uint64_t wave_id =
+        (uint64_t)blockIdx.x * waves_per_wg + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
     const uint32_t idx_mask = P.bitmap_words * 32 - 1;
 
     const uint64_t base0 = P.lo & ~1023ull; // chunks are 1 KiB aligned relative to text[0]
     const uint64_t n_chunks = (P.hi - base0 + 1023) / 1024;
-    const uint64_t span = P.span_chunks;
+    const uint64_t n_whole = (P.hi - base0) / 1024; // chunks that lie fully inside the text
+    const uint64_t span = P.span_chunks;            // multiple of U (host guarantees)
     const uint64_t n_spans = (n_chunks + span - 1) / span;
-
-    constexpr int NWIN = 16 / S;
+    const uint8_t *lane_text = P.text + base0 + (uint64_t)lane * 16;
 
     for (uint64_t sp = wave_id; sp < n_spans; sp += n_waves) {
         const uint64_t c_begin = sp * span;
@@ -131,104 +281,37 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
         uint32_t carry_in = 0;
         {
             const uint64_t cb = base0 + c_begin * 1024;
-            if (cb >= 16 && cb - 16 >= (P.lo & ~15ull) && lane == 0)
+            if (cb >= 16 && lane == 0)
                 carry_in = pack16(load_text16(P.text, cb - 16, P.hi));
             carry_in = __builtin_amdgcn_readfirstlane(carry_in);
         }
-        uint4 v_next = load_text16(P.text, base0 + c_begin * 1024 + (uint64_t)lane * 16, P.hi);
-        for (uint64_t ch = c_begin; ch < c_end; ++ch) {
-            const uint64_t L = base0 + ch * 1024 + (uint64_t)lane * 16;
-            const uint4 v = v_next;
-            if (ch + 1 < c_end)
-                v_next = load_text16(P.text, L + 1024, P.hi);
-            const uint32_t w = pack16(v);
-            uint32_t prev = __builtin_amdgcn_update_dpp(0u, w, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
-            if (lane == 0)
-                prev = carry_in;
-            carry_in = __builtin_amdgcn_readlane(w, 63);
-
-            // windows d = S, 2S, .., 16: text start t = L - 16 + d, key = bits [2d, 2d+32) of (w:prev)
-            uint32_t pos_mask = 0;
+        // ---- fast path: whole groups ----
+        uint64_t ch = c_begin;
+        const uint64_t whole_end = c_end < n_whole ? c_end : n_whole;
+        const uint64_t fast_end = c_begin + (whole_end > c_begin ? (whole_end - c_begin) / U * U : 0);
+        if (ch < fast_end) {
+            uint4 nxt[U];
 #pragma unroll
-            for (int i = 0; i < NWIN; ++i) {
-                const int d = S * (i + 1);
-                const uint32_t key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
-                const uint32_t h = bloom_hash(key, 0) & idx_mask;
-                const uint32_t word = lds[h >> 5];
-                pos_mask |= ((word >> (h & 31)) & 1u) << i;
-            }
-            // cascade: further probes only for survivors
-            for (uint32_t pr = 1; pr < P.n_probes; ++pr) {
-                if (__ballot(pos_mask != 0) == 0)
-                    break;
-                uint32_t keep = 0;
+            for (int u = 0; u < U; ++u)
+                nxt[u] = load16_stream<NT>(lane_text + (ch + u) * 1024);
+            for (; ch < fast_end; ch += U) {
+                uint4 cur[U];
 #pragma unroll
-                for (int i = 0; i < NWIN; ++i) {
-                    if (pos_mask & (1u << i)) {
-                        const int d = S * (i + 1);
-                        const uint32_t key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
-                        const uint32_t h = bloom_hash(key, pr) & idx_mask;
-                        const uint32_t word = lds[h >> 5];
-                        keep |= ((word >> (h & 31)) & 1u) << i;
-                    }
-                }
-                pos_mask = keep;
+                for (int u = 0; u < U; ++u)
+                    cur[u] = nxt[u];
+                // prefetch unconditionally; past the last group re-read the current one (stays in bounds)
+                const uint64_t pf = ch + U < fast_end ? ch + U : ch;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    nxt[u] = load16_stream<NT>(lane_text + (pf + u) * 1024);
+                filter_group<S, U, HV>(P, cur, base0 + ch * 1024, carry_in, lane, lds, idx_mask);
             }
-            // survivors: exact key table
-            while (__ballot(pos_mask != 0) != 0) {
-                bool emit = false;
-                uint64_t t = 0;
-                uint32_t val = 0;
-                uint32_t key = 0;
-                uint32_t slot = 0;
-                bool probing = false;
-                if (pos_mask != 0) {
-                    const int i = __ffs(pos_mask) - 1;
-                    pos_mask &= pos_mask - 1;
-                    const int d = S * (i + 1);
-                    key = d == 16 ? w : alignbit(w, prev, (2 * d) & 31);
-                    const int64_t ts = (int64_t)L - 16 + d;
-                    if (ts >= (int64_t)P.lo && (uint64_t)ts + kKeyH <= P.hi) {
-                        t = (uint64_t)ts;
-                        slot = ht_hash(key) & P.ht_mask;
-                        probing = true;
-                    }
-                }
-                while (__ballot(probing) != 0) {
-                    emit = false;
-                    if (probing) {
-                        const uint2 e = P.ht[slot];
-                        if (e.y == kHtEmpty) {
-                            probing = false;
-                        } else {
-                            if (e.x == key) {
-                                emit = true;
-                                val = e.y;
-                            }
-                            slot = (slot + 1) & P.ht_mask;
-                        }
-                    }
-                    const uint64_t m = __ballot(emit);
-                    if (m != 0) {
-                        const uint32_t n = __popcll(m);
-                        const int leader = __ffsll((unsigned long long)m) - 1;
-                        unsigned long long base = 0;
-                        if ((int)lane == leader)
-                            base = atomicAdd(&P.counters[1], (unsigned long long)n);
-                        base = __shfl(base, leader);
-                        if (emit) {
-                            const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
-                            if (idx < P.cand_cap) {
-                                candidate c;
-                                c.t = t;
-                                c.val = val;
-                                c.pad = 0;
-                                P.cand[idx] = c;
-                            }
-                        }
-                    }
-                }
-            }
+        }
+        // ---- ragged end ----
+        for (; ch < c_end; ++ch) {
+            uint4 one[1];
+            one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
+            filter_group<S, 1, HV>(P, one, base0 + ch * 1024, carry_in, lane, lds, idx_mask);
         }
     }
 }

@@ -31,6 +31,7 @@ struct filter_index
     uint32_t stride = 0;
     uint32_t bitmap_words = 0;
     uint32_t n_probes = 0;
+    uint32_t hash_variant = 0;
     uint32_t ht_mask = 0;
     uint64_t n_keys = 0;
     uint32_t *d_bitmap = nullptr;
@@ -134,9 +135,10 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
     F.bitmap_words = words;
     std::vector<uint32_t> bitmap(words, 0);
     const uint32_t idx_mask = words * 32 - 1;
+    F.hash_variant = (uint32_t)(env_int("SPM_HIP_FILTER_HASH", 1) ? 1 : 0);
     for (const kv &e : keys)
         for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
-            const uint32_t h = bloom_hash(e.key, pr) & idx_mask;
+            const uint32_t h = (F.hash_variant ? bloom_hash<1>(e.key, pr) : bloom_hash<0>(e.key, pr)) & idx_mask;
             bitmap[h >> 5] |= 1u << (h & 31);
         }
     uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_keys * 2));
@@ -465,6 +467,13 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
         return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (hits_block &b : ctx->pool) {
+        hipFree(b.d_hits);
+        hipFree(b.d_count);
+        for (int e = 0; e < 4; ++e)
+            if (b.ev[e])
+                hipEventDestroy(b.ev[e]);
+    }
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
@@ -804,19 +813,49 @@ int run_filter(const scan_args &A)
     const int fs = env_int("SPM_HIP_FILTER_SPAN", 0);
     if (fs > 0)
         span = (uint64_t)fs;
+    span = (span + 7) & ~7ull; // whole groups of chunks
     P.span_chunks = (uint32_t)span;
 
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
-#define LAUNCH_FILTER(S)                                                                                               \
-    hipFuncSetAttribute((const void *)seed_filter_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-    hipLaunchKernelGGL((seed_filter_kernel<S>), dim3(grid), dim3(threads), lds, ctx->stream, P)
+    const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
+    const bool NT = env_int("SPM_HIP_FILTER_NT", 1) != 0;
+    P.hash_variant = F.hash_variant;
+#define LAUNCH_FILTER3(S, UU, NTT, HV)                                                                                 \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV>,                                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_kernel<S, UU, NTT, HV>), dim3(grid), dim3(threads), lds, ctx->stream, P);      \
+    } while (0)
+#define LAUNCH_FILTER2(S, UU)                                                                                          \
+    do {                                                                                                               \
+        if (NT) {                                                                                                      \
+            if (F.hash_variant)                                                                                        \
+                LAUNCH_FILTER3(S, UU, true, 1);                                                                        \
+            else                                                                                                       \
+                LAUNCH_FILTER3(S, UU, true, 0);                                                                        \
+        } else {                                                                                                       \
+            if (F.hash_variant)                                                                                        \
+                LAUNCH_FILTER3(S, UU, false, 1);                                                                       \
+            else                                                                                                       \
+                LAUNCH_FILTER3(S, UU, false, 0);                                                                       \
+        }                                                                                                              \
+    } while (0)
+#define LAUNCH_FILTER(S, UMAX)                                                                                         \
+    do {                                                                                                               \
+        if (U >= 8 && UMAX >= 8)                                                                                       \
+            LAUNCH_FILTER2(S, (UMAX >= 8 ? 8 : UMAX));                                                                 \
+        else                                                                                                           \
+            LAUNCH_FILTER2(S, (UMAX >= 4 ? 4 : UMAX));                                                                 \
+    } while (0)
     switch (F.stride) {
-    case 16: LAUNCH_FILTER(16); break;
-    case 8: LAUNCH_FILTER(8); break;
-    case 4: LAUNCH_FILTER(4); break;
-    case 2: LAUNCH_FILTER(2); break;
-    default: LAUNCH_FILTER(1); break;
+    case 16: LAUNCH_FILTER(16, 8); break;
+    case 8: LAUNCH_FILTER(8, 8); break;
+    case 4: LAUNCH_FILTER(4, 8); break;
+    case 2: LAUNCH_FILTER(2, 4); break;
+    default: LAUNCH_FILTER(1, 2); break;
     }
+#undef LAUNCH_FILTER2
+#undef LAUNCH_FILTER3
 #undef LAUNCH_FILTER
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
@@ -870,11 +909,28 @@ extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, 
     std::unique_ptr<spm_hits, void (*)(spm_hits *)> H(new spm_hits, spm_hip_hits_destroy);
     H->ctx = ctx;
     H->cap = opts.max_hits ? opts.max_hits : (1ull << 20);
-    SPM_HIP_CHECK(ctx, hipMalloc(&H->d_hits, std::max<uint64_t>(H->cap, 1) * sizeof(spm_hit)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 8 * sizeof(unsigned long long)));
+    {
+        // recycle the buffers of an earlier scan (hipMalloc/hipEventCreate per scan cost ~0.2 ms)
+        bool reused = false;
+        for (size_t i = 0; i < ctx->pool.size(); ++i)
+            if (ctx->pool[i].cap == H->cap) {
+                const hits_block b = ctx->pool[i];
+                ctx->pool.erase(ctx->pool.begin() + i);
+                H->d_hits = b.d_hits;
+                H->d_count = b.d_count;
+                for (int e = 0; e < 4; ++e)
+                    H->ev[e] = b.ev[e];
+                reused = true;
+                break;
+            }
+        if (!reused) {
+            SPM_HIP_CHECK(ctx, hipMalloc(&H->d_hits, std::max<uint64_t>(H->cap, 1) * sizeof(spm_hit)));
+            SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 8 * sizeof(unsigned long long)));
+            for (int i = 0; i < 4; ++i)
+                SPM_HIP_CHECK(ctx, hipEventCreate(&H->ev[i]));
+        }
+    }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    for (int i = 0; i < 4; ++i)
-        SPM_HIP_CHECK(ctx, hipEventCreate(&H->ev[i]));
 
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
 
@@ -1081,13 +1137,23 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
 {
     if (!h)
         return;
-    if (h->ctx)
-        hipStreamSynchronize(h->ctx->stream);
-    hipFree(h->d_hits);
-    hipFree(h->d_count);
-    for (int i = 0; i < 6; ++i)
-        if (h->ev[i])
-            hipEventDestroy(h->ev[i]);
+    if (h->ctx && h->d_hits && h->d_count && h->ev[3] && h->ctx->pool.size() < 8) {
+        hits_block b;
+        b.d_hits = h->d_hits;
+        b.d_count = h->d_count;
+        b.cap = h->cap;
+        for (int e = 0; e < 4; ++e)
+            b.ev[e] = h->ev[e];
+        h->ctx->pool.push_back(b); // stream order makes reuse by the next scan safe
+    } else {
+        if (h->ctx)
+            hipStreamSynchronize(h->ctx->stream);
+        hipFree(h->d_hits);
+        hipFree(h->d_count);
+        for (int i = 0; i < 6; ++i)
+            if (h->ev[i])
+                hipEventDestroy(h->ev[i]);
+    }
     delete h;
 }
 
