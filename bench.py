@@ -98,11 +98,17 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+    backend = os.environ.get("SPM_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     algo, L, kmax, n_pat, gib, desc = WORKLOADS[args.workload]
     if args.text_gib is not None:
@@ -173,6 +179,15 @@ def main():
             k_ms = ms_main / max(launches, 1)  # average duration of one launch of the dominant kernel
             achieved = (hi - lo) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             engine_used = {1: "brute", 2: "filter"}.get(int(st.engine_used), "?")
+            # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, corrected as the MI355X guide
+            # prescribes; profiles/pmc_traffic.json says how) -- only when it was measured on this exact config
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+                if pm and pm["text_bytes_per_gpu"] == hi - lo and engine_used == "filter":
+                    traffic = pm["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             result = {
                 "metric": "Gbases/s scanned, Myers k<=3 |P|=100" if args.workload == "c3"
                           else "Gbases/s scanned, Shift-Or |P|=32",
@@ -197,7 +212,7 @@ def main():
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic,
                     "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_brute_kernel",
                     "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": hi - lo,

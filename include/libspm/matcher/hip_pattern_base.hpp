@@ -1,0 +1,178 @@
+// libspm/matcher/hip_pattern_base.hpp -- CRTP driver shared by all matchers.
+//
+// Mirrors /root/reference/libspm/libspm/matcher/seqan_pattern_base.hpp:27-100: operator()(haystack, callback) adapts
+// the haystack, runs the search and invokes callback(finder) once per hit in ascending position; empty(); default
+// window_size = |needle| (0 when empty, :97-99).  Instead of driving seqan2::find symbol by symbol on the host it
+// hands the haystack (1-byte ranks) to libspm_hip.so, which scans it in bulk on the MI355X, and then replays the hits
+// in order.  `finder` is what the callback receives; seqan2::beginPosition / endPosition / position / length are
+// provided for it so that call sites written against the reference compile unchanged
+// (test/api/libspm/matcher/myers_matcher_test.cpp:49-51, horspool_matcher_test.cpp:48-50).
+#pragma once
+
+#include <algorithm>
+#include <concepts>
+#include <cstring>
+#include <ranges>
+#include <vector>
+
+#include <libspm/hip/context.hpp>
+#include <libspm/matcher/concept.hpp>
+#include <libspm/seqan/alphabet.hpp>
+
+namespace spm
+{
+// What the per-hit callback receives (stands in for seqan2::Finder<haystack>).
+class finder
+{
+    std::size_t _begin{}, _end{}, _haystack_length{};
+    int _score{};
+
+public:
+    constexpr finder() = default;
+    constexpr finder(std::size_t b, std::size_t e, std::size_t n, int score) noexcept :
+        _begin{b}, _end{e}, _haystack_length{n}, _score{score}
+    {}
+    constexpr std::size_t begin_position() const noexcept { return _begin; }
+    constexpr std::size_t end_position() const noexcept { return _end; }
+    constexpr std::size_t haystack_length() const noexcept { return _haystack_length; }
+    // edit distance of this hit (0 for exact matchers); the reference exposes it only as the pattern state's errors
+    constexpr int score() const noexcept { return -_score; }
+    constexpr int errors() const noexcept { return _score; }
+};
+
+namespace detail
+{
+    template <typename symbol_t>
+    constexpr std::uint32_t sigma_of() noexcept
+    {
+        if constexpr (requires { std::remove_cvref_t<symbol_t>::alphabet_size; })
+            return static_cast<std::uint32_t>(std::remove_cvref_t<symbol_t>::alphabet_size);
+        else
+            return 255; // plain integral symbols: ranks must be < 255
+    }
+
+    template <std::ranges::input_range range_t>
+    std::vector<std::uint8_t> to_ranks(range_t && r)
+    {
+        std::vector<std::uint8_t> v;
+        if constexpr (std::ranges::sized_range<range_t>)
+            v.reserve(std::ranges::size(r));
+        for (auto && s : r)
+            v.push_back(static_cast<std::uint8_t>(static_cast<unsigned>(s)));
+        return v;
+    }
+
+    // Contiguous ranges of 1-byte symbols are handed over without a host copy.
+    template <typename range_t>
+    concept byte_contiguous = std::ranges::contiguous_range<range_t> && std::ranges::sized_range<range_t> &&
+                              sizeof(std::ranges::range_value_t<range_t>) == 1;
+} // namespace detail
+
+template <typename derived_t>
+class hip_pattern_base
+{
+    friend derived_t;
+
+protected:
+    hip_pattern_base() = default;
+    std::vector<std::uint8_t> _needle{}; // owned copy of the needle ranks (safe superset of the reference's view)
+    std::uint32_t _sigma{4};
+    std::uint32_t _errors{0};
+    hip::patterns_ptr _patterns{};
+
+    template <std::ranges::input_range needle_t>
+    void compile(needle_t && needle, int algo, std::uint32_t errors)
+    {
+        _needle = detail::to_ranks(needle);
+        _sigma = detail::sigma_of<std::ranges::range_value_t<needle_t>>();
+        _errors = errors;
+        std::uint32_t const offsets[2] = {0, static_cast<std::uint32_t>(_needle.size())};
+        std::uint16_t const k = static_cast<std::uint16_t>(std::min<std::uint32_t>(errors, 0xFFFF));
+        spm_patterns * p = nullptr;
+        std::uint8_t const dummy = 0;
+        if (spm_hip_patterns_create(hip::default_context(), algo, _needle.empty() ? &dummy : _needle.data(), offsets,
+                                    1, &k, _sigma, &p) != SPM_OK)
+            hip::fatal("spm_hip_patterns_create", hip::default_context());
+        _patterns = hip::patterns_ptr{p, hip::patterns_deleter{}};
+    }
+
+    // one bulk scan of `n` ranks; returns the hits in callback order
+    hip::hits_ptr scan(std::uint8_t const * ranks, std::size_t n, void const * state_in, void * state_out,
+                       hip::text_ptr * keep_text = nullptr) const noexcept
+    {
+        spm_ctx * ctx = hip::default_context();
+        spm_text * t = nullptr;
+        if (spm_hip_text_upload(ctx, ranks, n, _sigma, &t) != SPM_OK)
+            hip::fatal("spm_hip_text_upload", ctx);
+        hip::text_ptr text{t};
+        spm_scan_opts opts{};
+        opts.engine = SPM_ENGINE_AUTO;
+        spm_hits * h = nullptr;
+        if (spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &opts, state_in, state_out, &h) != SPM_OK)
+            hip::fatal("spm_hip_scan", ctx);
+        if (keep_text)
+            *keep_text = std::move(text);
+        return hip::hits_ptr{h};
+    }
+
+public:
+    // Note: non-const like the reference ("seqan use non-const pattern", seqan_pattern_base.hpp:39-41).
+    template <std::ranges::viewable_range haystack_t, typename callback_t>
+    void operator()(haystack_t && haystack, callback_t && callback) noexcept
+    {
+        if constexpr (detail::byte_contiguous<haystack_t>) {
+            static_cast<derived_t *>(this)->run(reinterpret_cast<std::uint8_t const *>(std::ranges::data(haystack)),
+                                                std::ranges::size(haystack), callback);
+        } else {
+            std::vector<std::uint8_t> const ranks = detail::to_ranks(haystack);
+            static_cast<derived_t *>(this)->run(ranks.data(), ranks.size(), callback);
+        }
+    }
+
+    bool empty() const noexcept { return _needle.empty(); }
+
+protected:
+    // default run(): fresh matcher every call (a fresh seqan2::Finder re-initialises the pattern)
+    template <typename callback_t>
+    void run(std::uint8_t const * ranks, std::size_t n, callback_t && callback) noexcept
+    {
+        hip::hits_ptr hits = scan(ranks, n, nullptr, nullptr);
+        replay(hits.get(), n, callback);
+    }
+
+    template <typename callback_t>
+    void replay(spm_hits * hits, std::size_t n, callback_t && callback) const noexcept
+    {
+        spm_hit const * rec = nullptr;
+        std::uint64_t cnt = 0;
+        if (spm_hip_hits_view(hits, &rec, &cnt) != SPM_OK)
+            hip::fatal("spm_hip_hits_view", hip::default_context());
+        std::size_t const m = _needle.size();
+        for (std::uint64_t i = 0; i < cnt; ++i) {
+            finder f = derived_t::reports_begin
+                           ? finder{static_cast<std::size_t>(rec[i].pos), static_cast<std::size_t>(rec[i].pos) + m, n, 0}
+                           : finder{rec[i].pos >= m ? static_cast<std::size_t>(rec[i].pos) - m : 0,
+                                    static_cast<std::size_t>(rec[i].pos), n, rec[i].score};
+            static_cast<derived_t const *>(this)->on_hit(f);
+            callback(f);
+        }
+    }
+
+    void on_hit(finder const &) const noexcept {}
+
+private:
+    constexpr friend std::size_t tag_invoke(std::tag_t<spm::window_size>, hip_pattern_base const & me) noexcept
+    {
+        return me._needle.size();
+    }
+};
+} // namespace spm
+
+// The names the reference's call sites use on the finder.
+namespace seqan2
+{
+inline std::size_t beginPosition(spm::finder const & f) noexcept { return f.begin_position(); }
+inline std::size_t endPosition(spm::finder const & f) noexcept { return f.end_position(); }
+inline std::size_t position(spm::finder const & f) noexcept { return f.begin_position(); }
+inline std::size_t length(spm::finder const & f) noexcept { return f.end_position() - f.begin_position(); }
+} // namespace seqan2

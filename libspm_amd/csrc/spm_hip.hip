@@ -1066,7 +1066,9 @@ extern "C" int spm_hip_hits_view(spm_hits *h, const spm_hit **records, uint64_t 
             SPM_HIP_CHECK(h->ctx, hipStreamSynchronize(h->ctx->stream));
         }
         std::sort(h->host.begin(), h->host.end(), [](const spm_hit &a, const spm_hit &b) {
-            return a.pattern != b.pattern ? a.pattern < b.pattern : a.pos < b.pos;
+            // positions compare as signed: a restored Shift-Or state can complete an occurrence that began before
+            // this chunk, whose begin position is "negative" (wrapped) relative to the chunk
+            return a.pattern != b.pattern ? a.pattern < b.pattern : (int64_t)a.pos < (int64_t)b.pos;
         });
         h->sorted_host = true;
     }

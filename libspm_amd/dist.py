@@ -30,6 +30,10 @@ def gatherv_hits(local: torch.Tensor, dst: int = 0, group=None):
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        # rehearsal path (gloo cannot send device tensors): stage through the host, same protocol
+        out = gatherv_hits(local.cpu(), dst, group)
+        return out.to(local.device) if out is not None else None
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)

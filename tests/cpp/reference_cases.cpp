@@ -1,0 +1,233 @@
+// reference_cases.cpp -- the reference's matcher test CASES (not its files) against the MI355X back-end, through the
+// C++ mirror of the spm:: API.  Sources of the cases:
+//   /root/reference/test/api/libspm/matcher/horspool_matcher_test.cpp:28-52
+//   /root/reference/test/api/libspm/matcher/shiftor_matcher_test.cpp:28-52
+//   /root/reference/test/api/libspm/matcher/myers_matcher_test.cpp:29-53
+//   /root/reference/test/api/libspm/matcher/myers_matcher_restorable_test.cpp:29-74
+//   /root/reference/test/api/libspm/seqan/alphabet_test.cpp:21-47 (rank/char contract; seqan3 concepts are not available)
+// plus cases for what the reference leaves untested (restorable Shift-Or, prefix matcher, dna5, capture inside a
+// callback, copies).  No gtest in this image: a 20-line EXPECT harness, exit code = number of failures.
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include <libspm/matcher/concept.hpp>
+#include <libspm/matcher/horspool_matcher.hpp>
+#include <libspm/matcher/myers_matcher.hpp>
+#include <libspm/matcher/myers_matcher_restorable.hpp>
+#include <libspm/matcher/myers_prefix_matcher_restorable.hpp>
+#include <libspm/matcher/shiftor_matcher.hpp>
+#include <libspm/matcher/shiftor_matcher_restorable.hpp>
+#include <libspm/seqan/alphabet.hpp>
+
+using spm::operator""_dna4;
+using spm::operator""_dna5;
+
+static int failures = 0;
+static int checks = 0;
+#define EXPECT_TRUE(cond)                                                                                              \
+    do {                                                                                                               \
+        ++checks;                                                                                                      \
+        if (!(cond)) {                                                                                                 \
+            ++failures;                                                                                                \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);                                              \
+        }                                                                                                              \
+    } while (0)
+#define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
+
+using sequence_t = std::vector<spm::dna4>;
+                            //0         1         2         3         4
+                            //012345678901234567890123456789012345678901234
+static sequence_t const haystack = "ACGTGACTAGCACGTGACTAGCACGTGACTAGCACGTGACTAGC"_dna4;
+static sequence_t const needle = "GCACG"_dna4;
+
+static void horspool_cases()
+{
+    std::vector<std::size_t> const expected{9, 20, 31};
+    auto matcher = spm::horspool_matcher{needle};
+    EXPECT_TRUE(spm::window_matcher<decltype(matcher)>);
+    EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle));
+    std::vector<std::size_t> actual{};
+    matcher(haystack, [&](auto const & finder) { actual.push_back(seqan2::beginPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(actual, expected));
+}
+
+static void shiftor_cases()
+{
+    std::vector<std::size_t> const expected{9, 20, 31};
+    auto matcher = spm::shiftor_matcher{needle};
+    EXPECT_TRUE(spm::window_matcher<decltype(matcher)>);
+    EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle));
+    std::vector<std::size_t> actual{};
+    matcher(haystack, [&](auto const & finder) { actual.push_back(seqan2::beginPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(actual, expected));
+    // the matcher is std::copyable and a copy is independent
+    auto copy = matcher;
+    actual.clear();
+    copy(haystack, [&](auto const & finder) { actual.push_back(seqan2::beginPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(actual, expected));
+}
+
+static void myers_cases()
+{
+    std::size_t const errors = 1;
+    std::vector<std::size_t> const expected{13, 14, 15, 24, 25, 26, 35, 36, 37};
+    std::vector<int> const expected_errors{1, 0, 1, 1, 0, 1, 1, 0, 1};
+    auto matcher = spm::myers_matcher{needle, errors};
+    EXPECT_TRUE(spm::window_matcher<decltype(matcher)>);
+    EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle) + errors);
+    std::vector<std::size_t> actual{};
+    std::vector<int> actual_errors{};
+    matcher(haystack, [&](auto const & finder) {
+        actual.push_back(seqan2::endPosition(finder));
+        actual_errors.push_back(finder.errors());
+    });
+    EXPECT_TRUE(std::ranges::equal(actual, expected));
+    EXPECT_TRUE(std::ranges::equal(actual_errors, expected_errors));
+    // default max_error_count = 0 -> exact occurrences only, reported by their exclusive end
+    auto exact = spm::myers_matcher{needle};
+    actual.clear();
+    exact(haystack, [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(actual, std::vector<std::size_t>{14, 25, 36}));
+    EXPECT_EQ(spm::window_size(exact), std::ranges::size(needle));
+}
+
+static void restorable_myers_cases()
+{
+    unsigned const errors = 1;
+    std::vector<std::size_t> const expected{13, 14, 15, 24, 25, 26, 35, 36, 37};
+    auto get_matcher = [&] { return spm::restorable_myers_matcher{needle, errors}; };
+    using matcher_t = decltype(get_matcher());
+    EXPECT_TRUE(spm::window_matcher<matcher_t>);
+    EXPECT_TRUE(spm::restorable_matcher<matcher_t>);
+    {
+        auto matcher = get_matcher();
+        EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle) + errors);
+        std::vector<std::size_t> actual{};
+        matcher(haystack, [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder)); });
+        EXPECT_TRUE(std::ranges::equal(actual, expected));
+    }
+    { // dna4_pattern_captured: chunks of 13, restore(state) before and capture() after each chunk
+        std::size_t const chunk_size{13};
+        std::ptrdiff_t const chunk_count = (haystack.size() + chunk_size - 1) / chunk_size;
+        auto matcher = get_matcher();
+        auto state = matcher.capture();
+        std::vector<std::size_t> actual{};
+        for (std::ptrdiff_t chunk_idx = 0; chunk_idx < chunk_count; ++chunk_idx) {
+            std::ptrdiff_t const offset = chunk_idx * chunk_size;
+            sequence_t chunk{haystack.begin() + offset,
+                             haystack.begin() + std::min<std::ptrdiff_t>(offset + chunk_size, haystack.size())};
+            matcher.restore(state);
+            matcher(chunk, [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder) + offset); });
+            state = matcher.capture();
+        }
+        EXPECT_TRUE(std::ranges::equal(actual, expected));
+    }
+    { // capture() inside the callback is the state AT that hit: resuming from it on the rest of the haystack
+      // yields exactly the remaining hits
+        auto matcher = get_matcher();
+        spm::matcher_state_t<matcher_t> at_fourth{};
+        std::size_t fourth_end = 0;
+        int seen = 0;
+        matcher(haystack, [&](auto const & finder) {
+            if (++seen == 4) {
+                at_fourth = spm::capture(matcher);
+                fourth_end = seqan2::endPosition(finder);
+            }
+        });
+        EXPECT_EQ(fourth_end, std::size_t{24});
+        EXPECT_EQ(at_fourth.errors(), 1);
+        auto resumed = get_matcher();
+        spm::restore(resumed, at_fourth);
+        sequence_t rest{haystack.begin() + fourth_end, haystack.end()};
+        std::vector<std::size_t> actual{};
+        resumed(rest, [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder) + fourth_end); });
+        EXPECT_TRUE(std::ranges::equal(actual, std::vector<std::size_t>{25, 26, 35, 36, 37}));
+    }
+}
+
+static void restorable_shiftor_cases()
+{
+    std::vector<std::size_t> const expected{9, 20, 31};
+    auto matcher = spm::restorable_shiftor_matcher{needle};
+    using matcher_t = decltype(matcher);
+    EXPECT_TRUE(spm::window_matcher<matcher_t>);
+    EXPECT_TRUE(spm::restorable_matcher<matcher_t>);
+    EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle));
+    for (std::size_t chunk_size : {44u, 13u, 11u, 5u, 3u}) {
+        auto m = spm::restorable_shiftor_matcher{needle};
+        auto state = m.capture();
+        std::vector<std::size_t> actual{};
+        for (std::size_t offset = 0; offset < haystack.size(); offset += chunk_size) {
+            sequence_t chunk{haystack.begin() + offset,
+                             haystack.begin() + std::min(offset + chunk_size, haystack.size())};
+            m.restore(state);
+            m(chunk, [&](auto const & finder) { actual.push_back(seqan2::beginPosition(finder) + offset); });
+            state = m.capture();
+        }
+        EXPECT_TRUE(std::ranges::equal(actual, expected));
+    }
+}
+
+static void prefix_cases()
+{
+    // needle vs. prefixes of the haystack: D[0][j] = j.  "GCACG" against "GCCGTT..." : prefix "GCCG" is 1 edit away.
+    sequence_t const hay = "GCCGTTTTTTTT"_dna4;
+    unsigned const errors = 1;
+    auto matcher = spm::restorable_myers_prefix_matcher{needle, errors};
+    EXPECT_TRUE(spm::window_matcher<decltype(matcher)>);
+    EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle) + errors);
+    std::vector<std::size_t> ends{};
+    std::vector<int> errs{};
+    matcher(hay, [&](auto const & finder) {
+        ends.push_back(seqan2::endPosition(finder));
+        errs.push_back(finder.errors());
+    });
+    // Sellers, global start: prefixes of length 4 (GCCG: 1 edit... delete A) and 5 (GCCGT: 2) -> only end 4 has <= 1
+    EXPECT_TRUE(std::ranges::equal(ends, std::vector<std::size_t>{4}));
+    EXPECT_TRUE(std::ranges::equal(errs, std::vector<int>{1}));
+    sequence_t const empty{};
+    auto none = spm::restorable_myers_prefix_matcher{empty, errors};
+    EXPECT_EQ(spm::window_size(none), std::size_t{0});
+    int calls = 0;
+    none(hay, [&](auto const &) { ++calls; });
+    EXPECT_EQ(calls, 0);
+}
+
+static void alphabet_cases()
+{
+    static_assert(sizeof(spm::dna4) == 1 && sizeof(spm::dna5) == 1 && sizeof(spm::dna15) == 1);
+    static_assert(std::semiregular<spm::dna4> && std::totally_ordered<spm::dna4>);
+    EXPECT_EQ(spm::alphabet_size_v<spm::dna4>, std::size_t{4});
+    EXPECT_EQ(spm::alphabet_size_v<spm::dna5>, std::size_t{5});
+    EXPECT_EQ(spm::alphabet_size_v<spm::dna15>, std::size_t{15});
+    auto s = "ACGTacgu"_dna4;
+    std::vector<int> ranks(s.begin(), s.end());
+    EXPECT_TRUE(std::ranges::equal(ranks, std::vector<int>{0, 1, 2, 3, 0, 1, 2, 3}));
+    EXPECT_EQ(static_cast<char>(spm::dna4{'G'}), 'G');
+    EXPECT_EQ(static_cast<int>(spm::dna5{'N'}), 3);
+    EXPECT_EQ(static_cast<int>(spm::dna5{'T'}), 4);
+    EXPECT_EQ(static_cast<int>(spm::dna5{'X'}), 3);
+    EXPECT_EQ(static_cast<char>(spm::dna15{std::uint8_t{14}}), 'Y');
+    EXPECT_TRUE(spm::dna4{'A'} < spm::dna4{'C'});
+    // dna5 haystack with N (brute engine: sigma = 5)
+    auto hay5 = "ACGNTACGNTAACGT"_dna5;
+    auto ndl5 = "ACGNT"_dna5;
+    auto m5 = spm::myers_matcher{ndl5, 0};
+    std::vector<std::size_t> ends{};
+    m5(hay5, [&](auto const & finder) { ends.push_back(seqan2::endPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(ends, std::vector<std::size_t>{5, 10}));
+}
+
+int main()
+{
+    horspool_cases();
+    shiftor_cases();
+    myers_cases();
+    restorable_myers_cases();
+    restorable_shiftor_cases();
+    prefix_cases();
+    alphabet_cases();
+    std::printf("%d checks, %d failures\n", checks, failures);
+    return failures;
+}
