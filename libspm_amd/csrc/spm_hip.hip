@@ -32,6 +32,8 @@ struct filter_index
     uint32_t bitmap_words = 0;
     uint32_t n_probes = 0;
     uint32_t hash_variant = 0;
+    uint32_t lds_words = 0;
+    uint32_t chd_slot_mask = 0, chd_bucket_shift = 0, chd_disp_off = 0;
     uint32_t ht_mask = 0;
     uint64_t n_keys = 0;
     uint32_t *d_bitmap = nullptr;
@@ -125,22 +127,100 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         return SPM_OK; // TODO(next): split the needle set into sub-batches, one text pass each
     F.stride = S;
     F.n_probes = (uint32_t)std::max(1, std::min(4, env_int("SPM_HIP_FILTER_PROBES", 4)));
-    uint64_t want_bits = F.n_keys * 32;
-    uint32_t words = 1024;
-    while ((uint64_t)words * 32 < want_bits && words < 32768)
-        words <<= 1;
-    const int force_w = env_int("SPM_HIP_FILTER_BITMAP_WORDS", 0);
-    if (force_w >= 256 && force_w <= 32768 && (force_w & (force_w - 1)) == 0)
-        words = (uint32_t)force_w;
-    F.bitmap_words = words;
-    std::vector<uint32_t> bitmap(words, 0);
-    const uint32_t idx_mask = words * 32 - 1;
-    F.hash_variant = (uint32_t)(env_int("SPM_HIP_FILTER_HASH", 1) ? 1 : 0);
-    for (const kv &e : keys)
-        for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
-            const uint32_t h = (F.hash_variant ? bloom_hash<1>(e.key, pr) : bloom_hash<0>(e.key, pr)) & idx_mask;
-            bitmap[h >> 5] |= 1u << (h & 31);
+    F.hash_variant = (uint32_t)std::max(0, std::min(2, env_int("SPM_HIP_FILTER_HASH", 2)));
+    std::vector<uint32_t> image; // what every workgroup stages into LDS
+    if (F.hash_variant == 2) {
+        // ---- perfect-hash fingerprint table (hash-and-displace, see filter.hpp) ----
+        std::vector<uint32_t> uniq;
+        uniq.reserve(keys.size());
+        for (const kv &e : keys)
+            uniq.push_back(e.key);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        uint32_t n_slots = 1024;
+        while (n_slots < 2 * uniq.size() && n_slots < 65536)
+            n_slots <<= 1;
+        bool ok = uniq.size() <= (size_t)(0.8 * n_slots);
+        const uint32_t n_buckets = std::max(64u, n_slots / 8);
+        uint32_t lg = 0;
+        while ((1u << lg) < n_buckets)
+            ++lg;
+        const uint32_t shift = 32 - lg;
+        std::vector<uint16_t> fp(n_slots, 0xFFFF), disp(n_buckets, 0);
+        if (ok) {
+            std::vector<std::vector<uint32_t>> buckets(n_buckets);
+            for (uint32_t k : uniq)
+                buckets[chd_hash(k).x >> shift].push_back(k);
+            std::vector<uint32_t> order(n_buckets);
+            for (uint32_t b = 0; b < n_buckets; ++b)
+                order[b] = b;
+            std::sort(order.begin(), order.end(),
+                      [&](uint32_t a, uint32_t b) { return buckets[a].size() > buckets[b].size(); });
+            std::vector<uint8_t> used(n_slots, 0);
+            std::vector<uint32_t> slots;
+            for (uint32_t b : order) {
+                const auto &B = buckets[b];
+                if (B.empty())
+                    break;
+                bool placed = false;
+                for (uint32_t d = 0; d < 65536 && !placed; ++d) {
+                    slots.clear();
+                    bool good = true;
+                    for (uint32_t k : B) {
+                        const uint32_t sl = chd_slot(chd_hash(k), d, n_slots - 1);
+                        if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) {
+                            good = false;
+                            break;
+                        }
+                        slots.push_back(sl);
+                    }
+                    if (good) {
+                        for (size_t i = 0; i < B.size(); ++i) {
+                            used[slots[i]] = 1;
+                            fp[slots[i]] = (uint16_t)chd_hash(B[i]).f;
+                        }
+                        disp[b] = (uint16_t)d;
+                        placed = true;
+                    }
+                }
+                if (!placed) {
+                    ok = false;
+                    break;
+                }
+            }
         }
+        if (ok) {
+            F.chd_slot_mask = n_slots - 1;
+            F.chd_bucket_shift = shift;
+            F.chd_disp_off = n_slots * 2;
+            image.resize((n_slots * 2 + n_buckets * 2) / 4);
+            memcpy(image.data(), fp.data(), n_slots * 2);
+            memcpy((uint8_t *)image.data() + n_slots * 2, disp.data(), n_buckets * 2);
+            F.bitmap_words = (uint32_t)image.size();
+        } else {
+            F.hash_variant = 1; // key set too dense for the fingerprint table: Bloom cascade
+        }
+    }
+    if (F.hash_variant != 2) {
+        uint64_t want_bits = F.n_keys * 32;
+        uint32_t words = 1024;
+        while ((uint64_t)words * 32 < want_bits && words < 32768)
+            words <<= 1;
+        const int force_w = env_int("SPM_HIP_FILTER_BITMAP_WORDS", 0);
+        if (force_w >= 256 && force_w <= 32768 && (force_w & (force_w - 1)) == 0)
+            words = (uint32_t)force_w;
+        F.bitmap_words = words;
+        image.assign(words, 0);
+        const uint32_t idx_mask = words * 32 - 1;
+        for (const kv &e : keys)
+            for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
+                const uint32_t hh = (F.hash_variant ? bloom_hash<1>(e.key, pr) : bloom_hash<0>(e.key, pr)) & idx_mask;
+                image[hh >> 5] |= 1u << (hh & 31);
+            }
+    }
+    F.lds_words = (uint32_t)image.size();
+    const uint32_t words = F.lds_words;
+    const std::vector<uint32_t> &bitmap = image;
     uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_keys * 2));
     F.ht_mask = ht_size - 1;
     std::vector<uint2> ht(ht_size, make_uint2(0, kHtEmpty));
@@ -794,7 +874,11 @@ int run_filter(const scan_args &A)
     P.lo = A.begin >= A.ctx_begin + reach ? A.begin - reach : A.ctx_begin;
     P.hi = A.end;
     P.stride = F.stride;
-    P.bitmap_words = F.bitmap_words;
+    P.bitmap_words = F.hash_variant == 2 ? 1024 : F.bitmap_words;
+    P.lds_words = F.lds_words;
+    P.chd_slot_mask = F.chd_slot_mask;
+    P.chd_bucket_shift = F.chd_bucket_shift;
+    P.chd_disp_off = F.chd_disp_off;
     P.n_probes = F.n_probes;
     P.bitmap = F.d_bitmap;
     P.ht = F.d_ht;
@@ -802,19 +886,23 @@ int run_filter(const scan_args &A)
     P.cand = d_cand;
     P.counters = H->d_count;
     P.cand_cap = cand_cap;
-    const uint32_t threads = (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", 1024)));
-    const size_t lds = (size_t)F.bitmap_words * 4;
+    const uint32_t threads = (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", 512)));
+    const size_t lds = (size_t)F.lds_words * 4 + 16; // + the workgroup's span-dequeue slot
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
     const uint64_t n_chunks = (P.hi - (P.lo & ~1023ull) + 1023) / 1024;
-    uint64_t span = n_chunks / (n_waves * 8) + 1;
-    span = std::min<uint64_t>(std::max<uint64_t>(span, 1), 4096);
+    uint64_t span = n_chunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 32))) + 1;
+    span = std::min<uint64_t>(std::max<uint64_t>(span, 8), 4096);
     const int fs = env_int("SPM_HIP_FILTER_SPAN", 0);
     if (fs > 0)
         span = (uint64_t)fs;
     span = (span + 7) & ~7ull; // whole groups of chunks
     P.span_chunks = (uint32_t)span;
+    // span dequeue: per wave while the dequeue rate stays far below what one atomic word sustains (~88/us, i.e.
+    // spans >= 192 KiB at 7 TB/s), per workgroup otherwise (measured: C3 2.52 vs 2.59 ms, C2 0.88 vs 0.20 ms)
+    const int dyn = env_int("SPM_HIP_FILTER_DYN", -1);
+    P.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (span >= 192 ? 1u : 2u);
 
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
     const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
@@ -829,12 +917,16 @@ int run_filter(const scan_args &A)
 #define LAUNCH_FILTER2(S, UU)                                                                                          \
     do {                                                                                                               \
         if (NT) {                                                                                                      \
-            if (F.hash_variant)                                                                                        \
+            if (F.hash_variant == 2)                                                                                   \
+                LAUNCH_FILTER3(S, UU, true, 2);                                                                        \
+            else if (F.hash_variant == 1)                                                                              \
                 LAUNCH_FILTER3(S, UU, true, 1);                                                                        \
             else                                                                                                       \
                 LAUNCH_FILTER3(S, UU, true, 0);                                                                        \
         } else {                                                                                                       \
-            if (F.hash_variant)                                                                                        \
+            if (F.hash_variant == 2)                                                                                   \
+                LAUNCH_FILTER3(S, UU, false, 2);                                                                       \
+            else if (F.hash_variant == 1)                                                                              \
                 LAUNCH_FILTER3(S, UU, false, 1);                                                                       \
             else                                                                                                       \
                 LAUNCH_FILTER3(S, UU, false, 0);                                                                       \
@@ -925,12 +1017,12 @@ extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, 
             }
         if (!reused) {
             SPM_HIP_CHECK(ctx, hipMalloc(&H->d_hits, std::max<uint64_t>(H->cap, 1) * sizeof(spm_hit)));
-            SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 8 * sizeof(unsigned long long)));
+            SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 16 * sizeof(unsigned long long)));
             for (int i = 0; i < 4; ++i)
                 SPM_HIP_CHECK(ctx, hipEventCreate(&H->ev[i]));
         }
     }
-    SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
 
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
 
@@ -968,7 +1060,7 @@ extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, 
         if (c[1] > H->cand_cap || c[2] != 0) {
             H->stats.fell_back = 1;
             use_filter = false;
-            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
         } else {
             H->n = c[0];
             H->counted = true;
