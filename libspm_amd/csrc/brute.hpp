@@ -271,6 +271,212 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Myers with Ukkonen cut-off, one lane per needle (stateless scans: the throughput case).
+//
+// The reference's large-pattern path only computes the blocks inside the band of cells that can still be <= k
+// ([upstream] _findMyersLargePatterns, reached from myers_matcher_restorable.hpp:53-54); this is the same idea at
+// 32-row granularity, per lane:
+//   a    = number of active words (rows 0 .. 32a-1), S = D at the bottom row of word a-1 in the current column
+//   grow   before a column, if S <= k and a < nw: word a enters with vertical deltas +1 (an over-estimate of cells
+//          that are all > k, which keeps every cell whose true value is <= k exact -- Myers 1999, sec. 4)
+//   shrink after a column, while a > 1 and S >= k + rows(a-1): the whole last word is > k; S moves up by the word's
+//          vertical deltas (popc(VP) - popc(VN))
+//   hit    a == nw and S <= k
+// Needles are BOTTOM-aligned here (row j at bit j) so that the band starts in word 0.  On random text with k <= 3
+// every lane sits at a = 1 almost always; the wave takes a one-word fast path then (amax == 1) and the general
+// masked multi-word path otherwise.  tests: brute-cutoff == brute-full == oracle.
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t rows = P.sigma + 1;
+    uint32_t *my_peq = lds + (size_t)wave_in_wg * rows * NW * 64; // [row][word][lane], bottom-aligned
+
+    const uint64_t n_items = (uint64_t)P.n_tiles * P.n_groups;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+
+    uint32_t loaded_group = 0xFFFFFFFFu;
+    int32_t my_m = 0, my_k = -1, my_nw = 1, my_lb = 0;
+
+    for (uint64_t item = wave_id; item < n_items; item += n_waves) {
+        const uint32_t group = (uint32_t)(item % P.n_groups);
+        const uint32_t tile = (uint32_t)(item / P.n_groups);
+        if (group != loaded_group) {
+            const uint32_t *src = P.peq + (size_t)group * rows * NW * 64;
+            for (uint32_t i = lane; i < rows * NW * 64; i += 64)
+                my_peq[i] = src[i];
+            my_m = P.m[group * 64 + lane];
+            my_k = my_m > 0 ? P.k[group * 64 + lane] : -1;
+            my_nw = my_m > 0 ? (my_m + 31) >> 5 : 1;
+            my_lb = my_m > 0 ? (my_m - 1) & 31 : 31;
+            loaded_group = group;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_hi = own_lo + P.tile;
+        if (own_hi > P.scan_end)
+            own_hi = P.scan_end;
+        const uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+
+        // ---- cold start: D[i][0] = i, band = rows with D <= k ----
+        uint32_t VP[NW], VN[NW];
+        int32_t a = my_k >= 0 ? (my_k >> 5) + 1 : 1;
+        if (a > my_nw)
+            a = my_nw;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            VP[w] = 0xFFFFFFFFu;
+            VN[w] = 0;
+        }
+        int32_t S = my_m > 0 ? (a == my_nw ? my_m : 32 * a) : 0x3FFFFFFF;
+        // derived per-lane values, refreshed whenever `a` changes
+        int32_t bp = a == my_nw ? my_lb : 31;                                  // bit of the band's bottom row
+        int32_t shrink_at = a > 1 ? my_k + (bp + 1) : 0x7FFFFFFF;              // S >= this: last word is all > k
+        int32_t amax = 1;                                                      // wave maximum of a (SGPR)
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+            if (__ballot(a > w) != 0)
+                amax = w + 1;
+        const uint32_t *lane_peq = my_peq + lane;
+        const uint32_t sigma = P.sigma;
+
+        auto adjust = [&](bool report, uint64_t pos) {
+            // slow path, entered when some lane has S <= k or S >= shrink_at
+            bool hit = (a == my_nw) && (S <= my_k);
+            if (report && __ballot(hit) != 0)
+                wave_append_hits(hit, pos, group * 64 + lane, S, P.hits, P.counters, P.hit_cap);
+            // shrink
+            while (a > 1 && S >= my_k + (bp + 1)) {
+                uint32_t vp = 0, vn = 0;
+#pragma unroll
+                for (int w = 1; w < NW; ++w)
+                    if (w == a - 1) {
+                        vp = VP[w];
+                        vn = VN[w];
+                    }
+                const uint32_t rm = bp == 31 ? 0xFFFFFFFFu : ((2u << bp) - 1);
+                S -= (int32_t)__popc(vp & rm) - (int32_t)__popc(vn & rm);
+                --a;
+                bp = 31;
+            }
+            // grow (for the next column)
+            if (a < my_nw && S <= my_k) {
+#pragma unroll
+                for (int w = 1; w < NW; ++w)
+                    if (w == a) {
+                        VP[w] = 0xFFFFFFFFu;
+                        VN[w] = 0;
+                    }
+                ++a;
+                bp = a == my_nw ? my_lb : 31;
+                S += bp + 1;
+            }
+            shrink_at = a > 1 ? my_k + (bp + 1) : 0x7FFFFFFF;
+            amax = 1;
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                if (__ballot(a > w) != 0)
+                    amax = w + 1;
+        };
+
+        auto step = [&](uint32_t c, bool report, uint64_t pos) {
+            const uint32_t *row = lane_peq + (size_t)c * NW * 64;
+            uint32_t hpl, hnl;
+            if (amax == 1) {
+                // every lane of the wave has a one-word band
+                const uint32_t eq = row[0];
+                const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[0], VP[0], 0xA8);
+                const uint32_t sum = VP[0] + t;
+                const uint32_t X = eq | VN[0];
+                const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, VP[0], X, 0xBE);
+                const uint32_t HN = VP[0] & D0;
+                const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN[0], VP[0], D0, 0xF1);
+                const uint32_t Xs = HP << 1;
+                const uint32_t Ts = HN << 1;
+                VN[0] = Xs & D0;
+                VP[0] = __builtin_amdgcn_bitop3_b32(Ts, Xs, D0, 0xF1);
+                hpl = HP;
+                hnl = HN;
+            } else {
+                uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
+                hpl = 0;
+                hnl = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    if (w < amax) {
+                        const uint32_t eq = row[w * 64];
+                        const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[w], VP[w], 0xA8);
+                        uint32_t cout;
+                        const uint32_t sum = __builtin_addc(VP[w], t, carry, &cout);
+                        const uint32_t X = eq | VN[w];
+                        const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, VP[w], X, 0xBE);
+                        const uint32_t HN = VP[w] & D0;
+                        const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN[w], VP[w], D0, 0xF1);
+                        const uint32_t Xs = alignbit(HP, hp_prev, 31);
+                        const uint32_t Ts = alignbit(HN, hn_prev, 31);
+                        const bool in_band = w < a; // lanes whose band ends earlier keep their (inactive) words
+                        if (in_band) {
+                            VN[w] = Xs & D0;
+                            VP[w] = __builtin_amdgcn_bitop3_b32(Ts, Xs, D0, 0xF1);
+                            carry = cout;
+                            hp_prev = HP;
+                            hn_prev = HN;
+                        }
+                        if (w == a - 1) {
+                            hpl = HP;
+                            hnl = HN;
+                        }
+                    }
+                }
+            }
+            S += (int32_t)((hpl >> bp) & 1) - (int32_t)((hnl >> bp) & 1);
+            if (__ballot(S <= my_k || S >= shrink_at) != 0)
+                adjust(report, pos);
+        };
+
+        const uint64_t a0 = scan_lo & ~3ull;
+        for (uint64_t cbase = a0; cbase < own_hi; cbase += 256) {
+            const uint64_t my_idx = cbase + (uint64_t)lane * 4;
+            uint32_t v = 0;
+            if (my_idx < own_hi)
+                v = load_text_dword(P.text, my_idx, P.text_alloc);
+            const uint64_t rem = own_hi - cbase;
+            const bool full = (cbase >= scan_lo) && (rem >= 256);
+            if (full && (cbase + 256 <= own_lo || cbase >= own_lo)) {
+                const bool report = cbase >= own_lo;
+                for (uint32_t j = 0; j < 64; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        c = c < sigma ? c : sigma;
+                        step(c, report, cbase + (uint64_t)j * 4 + s + 1 + P.pos_offset);
+                    }
+                }
+            } else {
+                const uint32_t n_dw = rem >= 256 ? 64u : (uint32_t)((rem + 3) / 4);
+                for (uint32_t j = 0; j < n_dw; ++j) {
+                    const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+                    for (int s = 0; s < 4; ++s) {
+                        const uint64_t p = cbase + (uint64_t)j * 4 + s;
+                        if (p < scan_lo || p >= own_hi)
+                            continue;
+                        uint32_t c = (w4 >> (8 * s)) & 0xFF;
+                        c = c < sigma ? c : sigma;
+                        step(c, p >= own_lo, p + 1 + P.pos_offset);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Shift-Or, NW 32-bit words per needle, one lane per needle
 // (replaces [upstream] _findShiftOrSmallNeedle/_findShiftOrLargeNeedle, shiftor_matcher_restorable.hpp:38-41).
 //   R = (R << 1) | mask[c];  occurrence ends here iff bit |P|-1 of R is 0.

@@ -57,7 +57,8 @@ struct spm_patterns
     uint32_t NB64 = 1; // 64-bit words per needle in the verify kernel (power of two)
     bool is_myers() const { return algo == SPM_ALGO_MYERS || algo == SPM_ALGO_MYERS_PREFIX; }
     // device
-    uint32_t *d_peq = nullptr; // [group][sigma+1][NW][64]
+    uint32_t *d_peq = nullptr; // [group][sigma+1][NW][64], needles top-aligned
+    uint32_t *d_peq_bot = nullptr; // Myers only: same shape, needles bottom-aligned (cut-off kernel)
     uint32_t *d_hp0 = nullptr; // prefix: [group][NW][64]
     int32_t *d_m = nullptr;
     int32_t *d_k = nullptr;
@@ -323,6 +324,17 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         }
     SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq, peq.size() * sizeof(uint32_t)));
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq, peq.data(), peq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (algo == SPM_ALGO_MYERS) {
+        std::vector<uint32_t> bot(peq.size(), 0);
+        for (uint32_t p = 0; p < n_patterns; ++p)
+            for (uint32_t j = 0; j < (uint32_t)ps->m[p]; ++j) {
+                const uint8_t c = ps->ranks[ps->offsets[p] + j];
+                if (c < sigma)
+                    bot[((((size_t)(p / 64)) * rows + c) * NW + j / 32) * 64 + (p % 64)] |= 1u << (j % 32);
+            }
+        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq_bot, bot.size() * sizeof(uint32_t)));
+        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq_bot, bot.data(), bot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (!hp0.empty()) {
         SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_hp0, hp0.size() * sizeof(uint32_t)));
         SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_hp0, hp0.data(), hp0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -357,6 +369,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     if (!p)
         return;
     hipFree(p->d_peq);
+    hipFree(p->d_peq_bot);
     hipFree(p->d_hp0);
     hipFree(p->d_m);
     hipFree(p->d_k);
@@ -706,9 +719,13 @@ struct scan_args
 
 template <int NW>
 void launch_brute_nw(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds,
-                     hipStream_t stream)
+                     hipStream_t stream, bool cutoff)
 {
-    if (ps->algo == SPM_ALGO_MYERS) {
+    if (cutoff) {
+        hipFuncSetAttribute((const void *)myers_cutoff_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        hipLaunchKernelGGL((myers_cutoff_kernel<NW>), grid, block, lds, stream, P);
+    } else if (ps->algo == SPM_ALGO_MYERS) {
         hipFuncSetAttribute((const void *)myers_brute_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         hipLaunchKernelGGL((myers_brute_kernel<NW, false>), grid, block, lds, stream, P);
@@ -723,16 +740,17 @@ void launch_brute_nw(const spm_patterns *ps, const brute_params &P, dim3 grid, d
     }
 }
 
-void launch_brute(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds, hipStream_t s)
+void launch_brute(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                  bool cutoff)
 {
     switch (ps->NW) {
-    case 1: launch_brute_nw<1>(ps, P, grid, block, lds, s); break;
-    case 2: launch_brute_nw<2>(ps, P, grid, block, lds, s); break;
-    case 4: launch_brute_nw<4>(ps, P, grid, block, lds, s); break;
-    case 8: launch_brute_nw<8>(ps, P, grid, block, lds, s); break;
-    case 16: launch_brute_nw<16>(ps, P, grid, block, lds, s); break;
-    case 32: launch_brute_nw<32>(ps, P, grid, block, lds, s); break;
-    default: launch_brute_nw<64>(ps, P, grid, block, lds, s); break;
+    case 1: launch_brute_nw<1>(ps, P, grid, block, lds, s, cutoff); break;
+    case 2: launch_brute_nw<2>(ps, P, grid, block, lds, s, cutoff); break;
+    case 4: launch_brute_nw<4>(ps, P, grid, block, lds, s, cutoff); break;
+    case 8: launch_brute_nw<8>(ps, P, grid, block, lds, s, cutoff); break;
+    case 16: launch_brute_nw<16>(ps, P, grid, block, lds, s, cutoff); break;
+    case 32: launch_brute_nw<32>(ps, P, grid, block, lds, s, cutoff); break;
+    default: launch_brute_nw<64>(ps, P, grid, block, lds, s, cutoff); break;
     }
 }
 
@@ -835,7 +853,12 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
         const uint32_t q = (launch_grid + ps->n_groups - 1) / ps->n_groups * ps->n_groups;
         launch_grid = std::min(grid, std::max(q, 1u));
     }
-    launch_brute(ps, P, dim3(launch_grid), dim3(64 * wpw), lds, ctx->stream);
+    // Ukkonen cut-off kernel for stateless Myers scans (SPM_HIP_BRUTE_CUTOFF=0 selects the full-width kernel)
+    const bool cutoff = ps->algo == SPM_ALGO_MYERS && !d_state_in && !d_state_out && ps->d_peq_bot &&
+                        env_int("SPM_HIP_BRUTE_CUTOFF", 1) != 0;
+    if (cutoff)
+        P.peq = ps->d_peq_bot;
+    launch_brute(ps, P, dim3(launch_grid), dim3(64 * wpw), lds, ctx->stream, cutoff);
     SPM_HIP_CHECK(ctx, hipGetLastError());
     A.hits->stats.main_launches++;
     return SPM_OK;

@@ -5,11 +5,11 @@ mkdir -p gpurun_out
 OUT=gpurun_out
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1 || { tail -40 $OUT/pytest_gpu.log; exit 1; }
 tail -2 $OUT/pytest_gpu.log
-for DYN in 2 1; do for w in c3 c2; do
-SPM_HIP_FILTER_DYN=$DYN timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --brute-sample-mib 0 2>&1 | python -c "
+for CUT in 1 0; do
+SPM_HIP_BRUTE_CUTOFF=$CUT timeout -k 10 300 python bench.py --engine brute --text-gib 0.5 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        r=json.loads(l); print('DYN=$DYN $w', round(r['value'],1), round(r['ms_per_step'],3), round(r['roofline']['kernel_ms'],3), round(r['roofline']['frac'],4), r['hits'], r['verify_ms_per_step'])
+        r=json.loads(l); print('CUT=$CUT brute', round(r['value'],3), round(r['ms_per_step'],3), r['hits'], r['all_planted_found'])
 "
-done; done
+done

@@ -219,3 +219,42 @@ def test_prefix_matcher(spm, ctx, oracle):
         assert got["pos"].tolist() == want["pos"].tolist()
         assert got["score"].tolist() == want["score"].tolist()
         assert len(want) >= 1
+
+
+@pytest.mark.parametrize("m,k", [(33, 1), (64, 3), (100, 3), (100, 40), (129, 5), (300, 10), (1024, 64)])
+def test_brute_cutoff_kernel_equals_full_kernel_and_oracle(spm, ctx, oracle, m, k):
+    """Ukkonen cut-off kernel (band of active 32-row words per lane) vs the full-width kernel vs the oracle, on a
+    text built to make the band grow and shrink constantly: long near-matches of needle prefixes."""
+    rng = np.random.default_rng(m * 131 + k)
+    n = 30000
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles = []
+    for i in range(70):
+        mm = m - (i % 5)
+        nd = rng.integers(0, 4, mm, dtype=np.uint8)
+        needles.append(nd)
+        # prefixes of many lengths (band grows, then dies), a few full occurrences with edits
+        for rep in range(6):
+            L = int(rng.integers(8, mm))
+            at = int(rng.integers(0, n - mm - 8))
+            piece = nd[:L].copy()
+            if L > 4 and rep % 2:
+                piece[L // 2] = (piece[L // 2] + 1) & 3
+            T[at:at + L] = piece
+        at = int(rng.integers(0, n - mm - 8))
+        occ = np.delete(nd, mm // 3) if i % 2 else nd
+        T[at:at + len(occ)] = occ
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    os.environ["SPM_HIP_BRUTE_CUTOFF"] = "0"
+    full = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view()
+    os.environ["SPM_HIP_BRUTE_CUTOFF"] = "1"
+    cut = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view()
+    del os.environ["SPM_HIP_BRUTE_CUTOFF"]
+    assert np.array_equal(full, cut)
+    sub = list(range(0, 70, 9))
+    want = _oracle_multi(oracle, "myers", T, [needles[i] for i in sub], [k] * len(sub))
+    got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(cut) if p in sub]
+    assert sorted(got) == want
+    if m <= 300:  # for |P| = 1024 the plantings overwrite each other in this short text
+        assert len(want) >= len(sub)
