@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (algo, |P|, kmax, needles, text GiB per GPU, description)
     "c3": ("myers", 100, 3, 1024, 16.0, "Myers k<=3, 1024 needles |P|=100, 16 GiB dna4 text per GPU"),
     "c2": ("shiftor", 32, 0, 1024, 1.0, "Shift-Or exact, 1024 needles |P|=32, 1 GiB dna4 text per GPU"),
+    "c4": ("myers", 150, 3, 100000, 8.0, "Myers k<=3, 100k needles |P|=150, 8 GiB dna4 text per GPU (64 GiB on 8)"),
 }
 
 
@@ -129,7 +130,7 @@ def main():
         s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR
         ps = ctx.patterns(s_algo, needles, k=kmax)
         engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
-        max_hits = 1 << 20
+        max_hits = max(1 << 20, 16 * n_pat)
         hit_buf = torch.empty((max_hits, 2), dtype=torch.int64, device=dev)
 
         def step():
@@ -189,8 +190,8 @@ def main():
             except Exception:
                 traffic = None
             result = {
-                "metric": "Gbases/s scanned, Myers k<=3 |P|=100" if args.workload == "c3"
-                          else "Gbases/s scanned, Shift-Or |P|=32",
+                "metric": {"c3": "Gbases/s scanned, Myers k<=3 |P|=100", "c2": "Gbases/s scanned, Shift-Or |P|=32",
+                           "c4": "Gbases/s scanned, Myers k<=3 |P|=150, 100k needles"}[args.workload],
                 "value": value,
                 "unit": "Gbases/s",
                 "n_gpus": world,

@@ -63,7 +63,8 @@ struct spm_patterns
     int32_t *d_m = nullptr;
     int32_t *d_k = nullptr;
     uint64_t *d_peq64 = nullptr; // verify: [pattern][4][NB64]
-    filter_index fidx;
+    std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
+    uint32_t filter_stride = 0;
 };
 
 static uint32_t next_pow2(uint32_t x)
@@ -80,34 +81,97 @@ static int env_int(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
+static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
+                           filter_index &F);
+
+// Seed filter applicability + partition of the needle set into sub-batches whose keys fit one LDS table.
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
-    filter_index &F = ps->fidx;
-    F.ok = false;
+    ps->fidx.clear();
     if (ps->sigma != 4 || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 || ps->n >= (1u << 21))
         return SPM_OK;
     uint32_t qmin = 0xFFFFFFFFu;
+    uint64_t n_seeds = 0;
     for (uint32_t p = 0; p < ps->n; ++p) {
         const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
         if (m == 0 || m > 2047)
             return SPM_OK;
         qmin = std::min(qmin, m / (k + 1));
+        n_seeds += k + 1;
     }
     if (qmin < kKeyH)
         return SPM_OK;
-    uint32_t S = 1;
-    while (S * 2 <= 16 && S * 2 <= qmin - (kKeyH - 1))
-        S *= 2;
+    uint32_t Smax = 1;
+    while (Smax * 2 <= 16 && Smax * 2 <= qmin - (kKeyH - 1))
+        Smax *= 2;
     const int force_s = env_int("SPM_HIP_FILTER_STRIDE", 0);
-    if (force_s > 0 && (uint32_t)force_s <= S)
-        S = (uint32_t)force_s;
+    if (force_s > 0 && (uint32_t)force_s <= Smax)
+        Smax = (uint32_t)force_s;
+    // keys per pass: the fingerprint table has 65536 slots and is built at <= 75 % load
+    const uint64_t cap = (uint64_t)std::max(1024, env_int("SPM_HIP_FILTER_MAX_KEYS", 49152));
+    // stride: the largest one when a single pass suffices; otherwise the one minimising passes x cost per pass
+    // (a pass with stride S looks at 16/S windows per 16 symbols; measured cost grows ~0.3x per doubling)
+    uint32_t S = Smax;
+    if (n_seeds * Smax > cap && force_s <= 0) {
+        double best = 1e300;
+        for (uint32_t s = Smax; s >= 1; s >>= 1) {
+            const double passes = (double)((n_seeds * s + cap - 1) / cap);
+            const double cost = passes * (1.0 + 0.3 * ((double)Smax / s - 1.0));
+            if (cost < best) {
+                best = cost;
+                S = s;
+            }
+        }
+    }
+    const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
+    ps->filter_stride = S;
+    uint32_t p0 = 0;
+    while (p0 < ps->n) {
+        uint64_t keys = 0;
+        uint32_t p1 = p0;
+        while (p1 < ps->n) {
+            const uint64_t add = (uint64_t)((ps->is_myers() ? ps->k[p1] : 0) + 1) * S;
+            if (keys + add > cap && p1 > p0)
+                break;
+            keys += add;
+            ++p1;
+        }
+        if (ps->fidx.size() >= max_passes) {
+            for (filter_index &F : ps->fidx) {
+                hipFree(F.d_bitmap);
+                hipFree(F.d_ht);
+            }
+            ps->fidx.clear();
+            return SPM_OK; // too many passes to be worth it: brute force
+        }
+        filter_index F;
+        int rc = build_one_index(ctx, ps, p0, p1, S, F);
+        if (rc != SPM_OK)
+            return rc;
+        if (!F.ok) {
+            for (filter_index &G : ps->fidx) {
+                hipFree(G.d_bitmap);
+                hipFree(G.d_ht);
+            }
+            ps->fidx.clear();
+            return SPM_OK;
+        }
+        ps->fidx.push_back(F);
+        p0 = p1;
+    }
+    return SPM_OK;
+}
 
+static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
+                           filter_index &F)
+{
+    F.ok = false;
     struct kv
     {
         uint32_t key, val;
     };
     std::vector<kv> keys;
-    for (uint32_t p = 0; p < ps->n; ++p) {
+    for (uint32_t p = p_begin; p < p_end; ++p) {
         const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
         const uint32_t q = m / (k + 1);
         const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
@@ -123,9 +187,8 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         }
     }
     F.n_keys = keys.size();
-    const uint64_t max_keys = (uint64_t)env_int("SPM_HIP_FILTER_MAX_KEYS", 1 << 18);
-    if (F.n_keys == 0 || F.n_keys > max_keys)
-        return SPM_OK; // TODO(next): split the needle set into sub-batches, one text pass each
+    if (F.n_keys == 0)
+        return SPM_OK;
     F.stride = S;
     F.n_probes = (uint32_t)std::max(1, std::min(4, env_int("SPM_HIP_FILTER_PROBES", 4)));
     F.hash_variant = (uint32_t)std::max(0, std::min(2, env_int("SPM_HIP_FILTER_HASH", 2)));
@@ -374,8 +437,10 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_m);
     hipFree(p->d_k);
     hipFree(p->d_peq64);
-    hipFree(p->fidx.d_bitmap);
-    hipFree(p->fidx.d_ht);
+    for (filter_index &F : p->fidx) {
+        hipFree(F.d_bitmap);
+        hipFree(F.d_ht);
+    }
     delete p;
 }
 
@@ -386,7 +451,7 @@ extern "C" uint64_t spm_hip_patterns_window_size(const spm_patterns *p, uint32_t
     return (uint64_t)p->m[pattern] + (p->is_myers() ? (uint64_t)p->k[pattern] : 0);
 }
 
-extern "C" int spm_hip_patterns_filterable(const spm_patterns *p) { return p && p->fidx.ok ? 1 : 0; }
+extern "C" int spm_hip_patterns_filterable(const spm_patterns *p) { return p && !p->fidx.empty() ? 1 : 0; }
 
 // ---- state blobs -------------------------------------------------------------------------------------
 static uint32_t abi_words(const spm_patterns *p)
@@ -868,13 +933,14 @@ int run_filter(const scan_args &A)
 {
     spm_ctx *ctx = A.ctx;
     const spm_patterns *ps = A.ps;
-    const filter_index &F = ps->fidx;
     spm_hits *H = A.hits;
     // scratch: candidates + dedupe set
     const uint64_t kmax = ps->max_k;
     uint64_t seen_slots = 1u << 20;
     uint64_t cand_cap = (seen_slots / 2) / (2 * kmax + 1);
     cand_cap = std::max<uint64_t>(cand_cap, 1024);
+    // every needle is expected to contribute a handful of true seed hits: scale with the set
+    cand_cap = std::max<uint64_t>(cand_cap, 8ull * ps->n * (kmax + 1));
     const int cc = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
     if (cc > 0)
         cand_cap = (uint64_t)cc;
@@ -896,6 +962,12 @@ int run_filter(const scan_args &A)
     const uint64_t reach = ps->max_window;
     P.lo = A.begin >= A.ctx_begin + reach ? A.begin - reach : A.ctx_begin;
     P.hi = A.end;
+    P.cand = d_cand;
+    P.counters = H->d_count;
+    P.cand_cap = cand_cap;
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
+    for (size_t fi = 0; fi < ps->fidx.size(); ++fi) {
+    const filter_index &F = ps->fidx[fi];
     P.stride = F.stride;
     P.bitmap_words = F.hash_variant == 2 ? 1024 : F.bitmap_words;
     P.lds_words = F.lds_words;
@@ -906,9 +978,8 @@ int run_filter(const scan_args &A)
     P.bitmap = F.d_bitmap;
     P.ht = F.d_ht;
     P.ht_mask = F.ht_mask;
-    P.cand = d_cand;
-    P.counters = H->d_count;
-    P.cand_cap = cand_cap;
+    if (fi > 0) // each pass draws its spans from a fresh head
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
     const uint32_t threads = (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", 512)));
     const size_t lds = (size_t)F.lds_words * 4 + 16; // + the workgroup's span-dequeue slot
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
@@ -927,7 +998,6 @@ int run_filter(const scan_args &A)
     const int dyn = env_int("SPM_HIP_FILTER_DYN", -1);
     P.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (span >= 192 ? 1u : 2u);
 
-    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
     const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
     const bool NT = env_int("SPM_HIP_FILTER_NT", 1) != 0;
     P.hash_variant = F.hash_variant;
@@ -973,8 +1043,9 @@ int run_filter(const scan_args &A)
 #undef LAUNCH_FILTER3
 #undef LAUNCH_FILTER
     SPM_HIP_CHECK(ctx, hipGetLastError());
-    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
     H->stats.main_launches++;
+    }
+    SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
 
     verify_params V{};
     V.text = A.text->d;
@@ -1050,8 +1121,8 @@ extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, 
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
 
     const bool has_state = state_in != nullptr;
-    const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && patterns->fidx.ok);
-    if (opts.engine == SPM_ENGINE_FILTER && (!patterns->fidx.ok || has_state)) {
+    const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && !patterns->fidx.empty());
+    if (opts.engine == SPM_ENGINE_FILTER && (patterns->fidx.empty() || has_state)) {
         SPM_SET_ERR(ctx, "spm_hip_scan: the seed filter does not apply to this needle set / a restored state");
         return SPM_E_UNSUPPORTED;
     }

@@ -4,6 +4,7 @@
 //   /root/reference/test/api/libspm/matcher/shiftor_matcher_test.cpp:28-52
 //   /root/reference/test/api/libspm/matcher/myers_matcher_test.cpp:29-53
 //   /root/reference/test/api/libspm/matcher/myers_matcher_restorable_test.cpp:29-74
+//   /root/reference/test/api/libspm/matcher/pigeonhole_matcher_test.cpp:20-85
 //   /root/reference/test/api/libspm/seqan/alphabet_test.cpp:21-47 (rank/char contract; seqan3 concepts are not available)
 // plus cases for what the reference leaves untested (restorable Shift-Or, prefix matcher, dna5, capture inside a
 // callback, copies).  No gtest in this image: a 20-line EXPECT harness, exit code = number of failures.
@@ -16,6 +17,7 @@
 #include <libspm/matcher/myers_matcher.hpp>
 #include <libspm/matcher/myers_matcher_restorable.hpp>
 #include <libspm/matcher/myers_prefix_matcher_restorable.hpp>
+#include <libspm/matcher/pigeonhole_matcher.hpp>
 #include <libspm/matcher/shiftor_matcher.hpp>
 #include <libspm/matcher/shiftor_matcher_restorable.hpp>
 #include <libspm/seqan/alphabet.hpp>
@@ -194,6 +196,52 @@ static void prefix_cases()
     EXPECT_EQ(calls, 0);
 }
 
+static void pigeonhole_cases()
+{
+    using needle_position_t = seqan2::PigeonholeSeedOnlyPosition;
+    sequence_t const needle2 = "TGACTAGCAC"_dna4;
+    std::vector<sequence_t> const multi_needle{needle, needle2};
+    double const errors = 0.0;
+    std::vector<std::size_t> const expected_positions{9, 20, 31};
+    std::vector<std::size_t> const expected_multi_positions{3, 8, 9, 14, 19, 20, 25, 30, 31, 36};
+    std::vector<needle_position_t> const expected_needle_positions{{1, 0, 5}, {1, 5, 5}, {0, 0, 5}, {1, 0, 5},
+                                                                   {1, 5, 5}, {0, 0, 5}, {1, 0, 5}, {1, 5, 5},
+                                                                   {0, 0, 5}, {1, 0, 5}};
+    {
+        auto matcher = spm::pigeonhole_matcher{needle, errors};
+        EXPECT_TRUE(spm::window_matcher<decltype(matcher)>);
+        EXPECT_EQ(spm::window_size(matcher), std::ranges::size(needle));
+        std::vector<std::size_t> actual{};
+        matcher(haystack, [&](auto const & finder) { actual.push_back(seqan2::beginPosition(finder)); });
+        EXPECT_TRUE(std::ranges::equal(actual, expected_positions));
+    }
+    {
+        auto matcher = spm::pigeonhole_matcher{multi_needle, errors};
+        std::vector<std::size_t> actual{};
+        std::vector<needle_position_t> actual_needle_positions{};
+        matcher(haystack, [&](auto const & finder) {
+            actual.push_back(seqan2::beginPosition(finder));
+            actual_needle_positions.push_back(matcher.position());
+        });
+        EXPECT_TRUE(std::ranges::equal(actual, expected_multi_positions));
+        EXPECT_TRUE(actual_needle_positions == expected_needle_positions);
+    }
+    { // seeds long enough for the device seed filter: 2 needles of 40, error rate 0.05 -> e = 2, q = 13 ... use 0.0 -> q = 40
+        std::vector<spm::dna4> hay;
+        for (int i = 0; i < 4000; ++i)
+            hay.emplace_back(static_cast<std::uint8_t>((i * 7 + (i >> 3) + (i >> 7)) & 3));
+        sequence_t n1(hay.begin() + 1000, hay.begin() + 1040), n2(hay.begin() + 2500, hay.begin() + 2540);
+        std::vector<sequence_t> const two{n1, n2};
+        auto matcher = spm::pigeonhole_matcher{two, 0.0};
+        EXPECT_EQ(spm::window_size(matcher), std::size_t{40});
+        std::vector<std::size_t> begins{};
+        matcher(hay, [&](auto const & finder) { begins.push_back(seqan2::beginPosition(finder)); });
+        EXPECT_TRUE(std::ranges::find(begins, std::size_t{1000}) != begins.end());
+        EXPECT_TRUE(std::ranges::find(begins, std::size_t{2500}) != begins.end());
+        EXPECT_TRUE(std::ranges::is_sorted(begins));
+    }
+}
+
 static void alphabet_cases()
 {
     static_assert(sizeof(spm::dna4) == 1 && sizeof(spm::dna5) == 1 && sizeof(spm::dna15) == 1);
@@ -227,6 +275,7 @@ int main()
     restorable_myers_cases();
     restorable_shiftor_cases();
     prefix_cases();
+    pigeonhole_cases();
     alphabet_cases();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures;

@@ -258,3 +258,33 @@ def test_brute_cutoff_kernel_equals_full_kernel_and_oracle(spm, ctx, oracle, m, 
     assert sorted(got) == want
     if m <= 300:  # for |P| = 1024 the plantings overwrite each other in this short text
         assert len(want) >= len(sub)
+
+
+def test_filter_sub_batches_equal_single_pass(spm, ctx, oracle):
+    """Needle sets whose keys outgrow one LDS table are split into sub-batches (one filter pass each, one
+    verification): same hits as the brute engine, whatever the split and stride."""
+    n = 1 << 22
+    text = ctx.generate(0x5EED0001, 0, n)
+    needles = _planted_config(spm, oracle, n, 300, 150, 3)
+    want = None
+    for max_keys, stride in ((None, None), (4096, None), (1500, 4), (1024, 1)):
+        if max_keys:
+            os.environ["SPM_HIP_FILTER_MAX_KEYS"] = str(max_keys)
+        if stride:
+            os.environ["SPM_HIP_FILTER_STRIDE"] = str(stride)
+        try:
+            ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+        finally:
+            os.environ.pop("SPM_HIP_FILTER_MAX_KEYS", None)
+            os.environ.pop("SPM_HIP_FILTER_STRIDE", None)
+        assert ps.filterable
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
+        st = h.stats()
+        assert st.fell_back == 0
+        if stride:  # forced stride: the key count exceeds the cap, so several passes are needed
+            assert st.main_launches > 1
+        got = h.view()
+        if want is None:
+            want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
+            assert len(want) >= 300
+        assert np.array_equal(got, want), (max_keys, stride)
