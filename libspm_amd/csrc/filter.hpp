@@ -431,6 +431,7 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
 struct verify_params
 {
     const uint8_t *text;
+    uint64_t text_alloc; // readable bytes from text
     uint64_t ctx_begin;  // first symbol of the haystack that may be consumed
     uint64_t scan_begin; // owned: last symbol index in [scan_begin, scan_end)
     uint64_t scan_end;
@@ -451,14 +452,20 @@ struct verify_params
     unsigned long long *overflow; // counters[2]
 };
 
+// One lane per candidate.  The lane's Peq rows are staged in LDS ([symbol][word][thread], conflict-free whatever the
+// per-lane symbol) and the text window is read 16 bytes at a time with the next block prefetched, so the per-symbol
+// dependency chain is one LDS read instead of two dependent global loads (0.09 ms -> see profiles for 20 k candidates).
 template <int NB>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
+    extern __shared__ uint64_t vlds[]; // [4][NB][blockDim.x]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthr = blockDim.x;
     unsigned long long n_cand = P.counters[1];
     if (n_cand > P.cand_cap)
         n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < n_cand; ci += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * nthr;
+    for (uint64_t ci = (uint64_t)blockIdx.x * nthr + tid; ci < n_cand; ci += stride) {
         const candidate c = P.cand[ci];
         const uint32_t pat = c.val >> 11;
         const int64_t x = c.val & 0x7FF;
@@ -479,7 +486,11 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         int64_t ws = e_lo - (m + k);
         if (ws < (int64_t)P.ctx_begin)
             ws = (int64_t)P.ctx_begin;
+        // stage this needle's Peq rows
         const uint64_t *peq = P.peq64 + (size_t)pat * 4 * NB;
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i)
+            vlds[(size_t)i * nthr + tid] = peq[i];
         uint64_t VP[NB], VN[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -490,61 +501,70 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         int32_t score = (int32_t)m;
         const int lastb = (int)((m - 1) >> 6);
         const int lastbit = (int)((m - 1) & 63);
-        for (int64_t p = ws; p < e_hi; ++p) {
-            const uint32_t sym = P.text[p] & 3;
-            uint64_t carry = 0, hp_c = 0, hn_c = 0;
-            uint64_t HPl = 0, HNl = 0;
+        const int64_t blk0 = ws & ~15ll;
+        uint4 nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
+        for (int64_t blk = blk0; blk < e_hi; blk += 16) {
+            const uint4 cur = nxt;
+            if (blk + 16 < e_hi)
+                nxt = load_text16(P.text, (uint64_t)(blk + 16), P.text_alloc);
+            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const uint64_t eq = peq[sym * NB + b];
-                const uint64_t X = eq | VN[b];
-                const uint64_t t1 = X & VP[b];
-                const uint64_t s1 = VP[b] + t1;
-                const uint64_t c1 = s1 < VP[b];
-                const uint64_t s2 = s1 + carry;
-                const uint64_t c2 = s2 < s1;
-                carry = c1 | c2;
-                const uint64_t D0 = (s2 ^ VP[b]) | X;
-                const uint64_t HN = VP[b] & D0;
-                const uint64_t HP = VN[b] | ~(VP[b] | D0);
-                const uint64_t Xs = (HP << 1) | hp_c;
-                const uint64_t Ts = (HN << 1) | hn_c;
-                hp_c = HP >> 63;
-                hn_c = HN >> 63;
-                VN[b] = Xs & D0;
-                VP[b] = Ts | ~(Xs | D0);
-                if (b == lastb) {
-                    HPl = HP;
-                    HNl = HN;
-                }
-            }
-            score += (int32_t)((HPl >> lastbit) & 1) - (int32_t)((HNl >> lastbit) & 1);
-            const int64_t e = p + 1;
-            if (score <= (int32_t)k && e >= e_lo) {
-                // dedupe across the seeds of one occurrence
-                const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
-                uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-                bool fresh = false;
-                for (uint32_t tries = 0; tries <= P.seen_mask; ++tries) {
-                    const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
-                    if (old == ~0ull) {
-                        fresh = true;
-                        break;
+            for (int i = 0; i < 16; ++i) {
+                const int64_t p = blk + i;
+                if (p < ws || p >= e_hi)
+                    continue;
+                const uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 3;
+                const uint64_t *row = vlds + ((size_t)sym * NB) * nthr + tid;
+                uint64_t carry = 0, hp_c = 0, hn_c = 0;
+                uint64_t HPl = 0, HNl = 0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const uint64_t eq = row[(size_t)b * nthr];
+                    const uint64_t X = eq | VN[b];
+                    const uint64_t t1 = X & VP[b];
+                    const uint64_t s1 = VP[b] + t1;
+                    const uint64_t c1 = s1 < VP[b];
+                    const uint64_t s2 = s1 + carry;
+                    const uint64_t c2 = s2 < s1;
+                    carry = c1 | c2;
+                    const uint64_t D0 = (s2 ^ VP[b]) | X;
+                    const uint64_t HN = VP[b] & D0;
+                    const uint64_t HP = VN[b] | ~(VP[b] | D0);
+                    const uint64_t Xs = (HP << 1) | hp_c;
+                    const uint64_t Ts = (HN << 1) | hn_c;
+                    hp_c = HP >> 63;
+                    hn_c = HN >> 63;
+                    VN[b] = Xs & D0;
+                    VP[b] = Ts | ~(Xs | D0);
+                    if (b == lastb) {
+                        HPl = HP;
+                        HNl = HN;
                     }
-                    if (old == key)
-                        break;
-                    slot = (slot + 1) & P.seen_mask;
-                    if (tries == P.seen_mask)
-                        atomicAdd(P.overflow, 1ull);
                 }
-                if (fresh) {
-                    const unsigned long long idx = atomicAdd(P.hit_counter, 1ull);
-                    if (idx < P.hit_cap) {
-                        spm_hit h;
-                        h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
-                        h.pattern = pat;
-                        h.score = score;
-                        P.hits[idx] = h;
+                score += (int32_t)((HPl >> lastbit) & 1) - (int32_t)((HNl >> lastbit) & 1);
+                const int64_t e = p + 1;
+                if (score <= (int32_t)k && e >= e_lo) {
+                    // dedupe across the seeds of one occurrence
+                    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
+                    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
+                    bool fresh = false;
+                    for (uint32_t tries = 0; tries <= P.seen_mask; ++tries) {
+                        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
+                        if (old == ~0ull) {
+                            fresh = true;
+                            break;
+                        }
+                        if (old == key)
+                            break;
+                        slot = (slot + 1) & P.seen_mask;
+                        if (tries == P.seen_mask)
+                            atomicAdd(P.overflow, 1ull);
+                    }
+                    if (fresh) {
+                        // the lanes that reach this point together share one atomic (ballot/popc); a per-hit
+                        // atomicAdd on the single counter costs ~11 ns each -- 4.6 ms for C4's 400 k hits
+                        wave_append_hits(true, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
+                                         score, P.hits, P.hit_counter, P.hit_cap);
                     }
                 }
             }

@@ -822,7 +822,11 @@ void launch_brute(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3
 template <int NB>
 void launch_verify_nb(const verify_params &V, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((verify_kernel<NB>), grid, dim3(256), 0, s, V);
+    // LDS holds 4*NB uint64 per thread; keep the block within 128 KiB
+    const uint32_t threads = NB <= 16 ? 256u : 128u;
+    const size_t lds = (size_t)4 * NB * 8 * threads;
+    hipFuncSetAttribute((const void *)verify_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((verify_kernel<NB>), grid, dim3(threads), lds, s, V);
 }
 
 void launch_verify(uint32_t NB, const verify_params &V, dim3 grid, hipStream_t s)
@@ -1049,6 +1053,7 @@ int run_filter(const scan_args &A)
 
     verify_params V{};
     V.text = A.text->d;
+    V.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
     V.ctx_begin = A.ctx_begin;
     V.scan_begin = A.begin;
     V.scan_end = A.end;
@@ -1066,7 +1071,7 @@ int run_filter(const scan_args &A)
     V.hit_counter = H->d_count;
     V.hit_cap = H->cap;
     V.overflow = H->d_count + 2;
-    launch_verify(ps->NB64, V, dim3(ctx->n_cu * 2), ctx->stream);
+    launch_verify(ps->NB64, V, dim3(ctx->n_cu * 4), ctx->stream);
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
     H->cand_cap = cand_cap;
