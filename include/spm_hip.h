@@ -138,6 +138,14 @@ int spm_hip_patterns_state_init(const spm_patterns *p, void *state);
 int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                  const spm_scan_opts *opts, const void *state_in, void *state_out, spm_hits **out);
 
+/* Batch of independent haystacks stored back to back in one text: haystack s = text[seg_offsets[s], seg_offsets[s+1])
+ * (n_segments + 1 ascending host offsets).  Each one is scanned as seqan_pattern_base::operator() would scan it on its
+ * own -- cold start at its first symbol, no hit spans two haystacks -- in ONE launch.  Positions are reported relative to
+ * text[0]; the caller maps them to (segment, local position).  Used by the journaled-sequence traversal, whose
+ * variant contexts are thousands of short haystacks. */
+int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const uint64_t *seg_offsets, uint64_t n_segments,
+                          const spm_patterns *patterns, const spm_scan_opts *opts, spm_hits **out);
+
 /* ---- hits ------------------------------------------------------------------------------------------ */
 /* Host view, sorted by (pattern, pos): per pattern this is the order the reference's callback fires in. */
 int spm_hip_hits_view(spm_hits *hits, const spm_hit **records, uint64_t *n);

@@ -92,6 +92,8 @@ def lib():
         "spm_hip_patterns_state_stride": (C.c_size_t, [vp]),
         "spm_hip_patterns_state_init": (C.c_int, [vp, vp]),
         "spm_hip_scan": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, C.POINTER(ScanOpts), vp, vp, C.POINTER(vp)]),
+        "spm_hip_scan_segments": (C.c_int, [vp, vp, C.POINTER(C.c_uint64), C.c_uint64, vp, C.POINTER(ScanOpts),
+                                            C.POINTER(vp)]),
         "spm_hip_hits_view": (C.c_int, [vp, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_uint64)]),
         "spm_hip_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "spm_hip_hits_copy_device": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -116,7 +118,7 @@ EXPORTS = [
     "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_download", "spm_hip_text_length",
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
-    "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_hits_view", "spm_hip_hits_device",
+    "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
     "spm_hip_hits_copy_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
     "spm_hip_mix64", "spm_hip_version",
 ]

@@ -41,6 +41,7 @@ struct brute_params
     uint32_t warm;         // warm-up symbols = max window - 1
     uint32_t sigma;        // rows 0..sigma-1 real symbols, row sigma = "no match" (invalid symbol)
     uint32_t has_state;    // 1: tile 0 continues from state_in instead of a cold start
+    const uint64_t *tile_tab; // segmented scans: per tile {scan_lo, own_lo, own_hi}; nullptr = regular tiling
     const uint32_t *peq;   // [group][sigma+1][NW][64]
     const uint32_t *hp0;   // prefix mode: [group][NW][64] carry-in mask (bit `off`), else nullptr
     const int32_t *m;      // [group*64] needle lengths (0 = padding lane)
@@ -171,11 +172,16 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
             __builtin_amdgcn_wave_barrier();
         }
         // ---- tile geometry (wave-uniform, SGPRs) ----
-        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
         uint64_t own_hi = own_lo + P.tile;
         if (own_hi > P.scan_end)
             own_hi = P.scan_end;
         uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        if (P.tile_tab) { // segmented haystacks: geometry comes from the host's tile table
+            scan_lo = P.tile_tab[3 * (uint64_t)tile];
+            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
+            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+        }
         const bool resume = P.has_state && tile == 0;
         if (resume)
             scan_lo = own_lo;
@@ -317,11 +323,16 @@ __global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
             loaded_group = group;
             __builtin_amdgcn_wave_barrier();
         }
-        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
         uint64_t own_hi = own_lo + P.tile;
         if (own_hi > P.scan_end)
             own_hi = P.scan_end;
-        const uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        if (P.tile_tab) {
+            scan_lo = P.tile_tab[3 * (uint64_t)tile];
+            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
+            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+        }
 
         // ---- cold start: D[i][0] = i, band = rows with D <= k ----
         uint32_t VP[NW], VN[NW];
@@ -512,11 +523,16 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
             loaded_group = group;
             __builtin_amdgcn_wave_barrier();
         }
-        const uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
+        uint64_t own_lo = P.scan_begin + (uint64_t)tile * P.tile;
         uint64_t own_hi = own_lo + P.tile;
         if (own_hi > P.scan_end)
             own_hi = P.scan_end;
         uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
+        if (P.tile_tab) { // segmented haystacks: geometry comes from the host's tile table
+            scan_lo = P.tile_tab[3 * (uint64_t)tile];
+            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
+            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+        }
         const bool resume = P.has_state && tile == 0;
         if (resume)
             scan_lo = own_lo;

@@ -69,6 +69,7 @@ struct spm_hits
     spm_scan_stats stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    void *d_aux[2] = {nullptr, nullptr}; // segmented scans: tile table, segment offsets (freed with the hits)
 };
 
 #define SPM_SET_ERR(ctx, ...)                                                                                          \

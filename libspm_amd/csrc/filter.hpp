@@ -450,6 +450,8 @@ struct verify_params
     unsigned long long *hit_counter; // counters[0]
     uint64_t hit_cap;
     unsigned long long *overflow; // counters[2]
+    const uint64_t *seg_offsets;  // segmented haystacks: n_segments+1 ascending offsets, or nullptr
+    uint64_t n_segments;
 };
 
 // One lane per candidate.  The lane's Peq rows are staged in LDS ([symbol][word][thread], conflict-free whatever the
@@ -476,16 +478,34 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         int64_t e_lo = d + m - k;
         int64_t e_hi = d + m + k;
         // ownership: last symbol e-1 in [scan_begin, scan_end)
-        if (e_lo < (int64_t)P.scan_begin + 1)
-            e_lo = (int64_t)P.scan_begin + 1;
-        if (e_hi > (int64_t)P.scan_end)
-            e_hi = (int64_t)P.scan_end;
+        int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
+        if (P.seg_offsets) {
+            // every segment is a haystack of its own: find the one holding the key window, clamp to it
+            uint64_t lo = 0, hi = P.n_segments; // invariant: seg_offsets[lo] <= t < seg_offsets[hi]
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (P.seg_offsets[mid] <= c.t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
+            if ((int64_t)c.t + (int64_t)kKeyH > se)
+                continue; // the key window straddles two haystacks
+            own_b = sb;
+            own_e = se;
+            hay_b = sb;
+        }
+        if (e_lo < own_b + 1)
+            e_lo = own_b + 1;
+        if (e_hi > own_e)
+            e_hi = own_e;
         if (e_lo > e_hi)
             continue;
         // cold start m+k symbols before the first end position (or at the haystack start)
         int64_t ws = e_lo - (m + k);
-        if (ws < (int64_t)P.ctx_begin)
-            ws = (int64_t)P.ctx_begin;
+        if (ws < hay_b)
+            ws = hay_b;
         // stage this needle's Peq rows
         const uint64_t *peq = P.peq64 + (size_t)pat * 4 * NB;
 #pragma unroll

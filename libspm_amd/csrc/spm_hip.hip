@@ -780,6 +780,8 @@ struct scan_args
     const void *state_in;
     void *state_out;
     spm_hits *hits;
+    const uint64_t *seg_offsets = nullptr; // host; n_segments + 1 entries
+    uint64_t n_segments = 0;
 };
 
 template <int NW>
@@ -910,6 +912,35 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
         tile = 4;
     P.tile = (uint32_t)std::min<uint64_t>(tile, 0xFFFFFF00u);
     P.n_tiles = (uint32_t)std::max<uint64_t>(1, (range + P.tile - 1) / P.tile);
+    if (A.seg_offsets) {
+        // every segment is its own haystack: tiles never cross a segment, warm-up stays inside it
+        std::vector<uint64_t> tab;
+        for (uint64_t s = 0; s < A.n_segments; ++s) {
+            const uint64_t sb = A.seg_offsets[s], se = A.seg_offsets[s + 1];
+            for (uint64_t lo = sb; lo < se; lo += P.tile) {
+                const uint64_t hi = std::min<uint64_t>(lo + P.tile, se);
+                tab.push_back(lo >= sb + P.warm ? lo - P.warm : sb);
+                tab.push_back(lo);
+                tab.push_back(hi);
+            }
+        }
+        if (tab.empty()) { // only empty segments
+            tab = {begin, begin, begin};
+        }
+        if (tab.size() / 3 > 0xFFFFFFFFull) {
+            SPM_SET_ERR(ctx, "segmented scan: too many tiles");
+            return SPM_E_UNSUPPORTED;
+        }
+        P.n_tiles = (uint32_t)(tab.size() / 3);
+        uint64_t *d_tab = nullptr;
+        SPM_HIP_CHECK(ctx, hipMalloc(&d_tab, tab.size() * sizeof(uint64_t)));
+        hipFree(A.hits->d_aux[0]);
+        A.hits->d_aux[0] = d_tab;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                          ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // `tab` is a host temporary
+        P.tile_tab = d_tab;
+    }
     if (single_tile && P.n_tiles != 1) {
         SPM_SET_ERR(ctx, "internal: single-tile pass over %llu symbols", (unsigned long long)range);
         return SPM_E_INVALID;
@@ -1071,6 +1102,16 @@ int run_filter(const scan_args &A)
     V.hit_counter = H->d_count;
     V.hit_cap = H->cap;
     V.overflow = H->d_count + 2;
+    if (A.seg_offsets) {
+        uint64_t *d_seg = nullptr;
+        SPM_HIP_CHECK(ctx, hipMalloc(&d_seg, (A.n_segments + 1) * sizeof(uint64_t)));
+        hipFree(H->d_aux[1]);
+        H->d_aux[1] = d_seg;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_seg, A.seg_offsets, (A.n_segments + 1) * sizeof(uint64_t),
+                                          hipMemcpyHostToDevice, ctx->stream));
+        V.seg_offsets = d_seg;
+        V.n_segments = A.n_segments;
+    }
     launch_verify(ps->NB64, V, dim3(ctx->n_cu * 4), ctx->stream);
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
@@ -1080,9 +1121,41 @@ int run_filter(const scan_args &A)
 
 } // namespace
 
+static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
+                     const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
+                     uint64_t n_segments, spm_hits **out);
+
 extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end,
                             const spm_patterns *patterns, const spm_scan_opts *opts_in, const void *state_in,
                             void *state_out, spm_hits **out)
+{
+    return scan_impl(ctx, text, begin, end, patterns, opts_in, state_in, state_out, nullptr, 0, out);
+}
+
+extern "C" int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const uint64_t *seg_offsets,
+                                     uint64_t n_segments, const spm_patterns *patterns, const spm_scan_opts *opts_in,
+                                     spm_hits **out)
+{
+    if (!ctx || !text || !seg_offsets || n_segments == 0) {
+        SPM_SET_ERR(ctx, "spm_hip_scan_segments: invalid argument");
+        return SPM_E_INVALID;
+    }
+    for (uint64_t s = 0; s < n_segments; ++s)
+        if (seg_offsets[s + 1] < seg_offsets[s] || seg_offsets[s + 1] > text->n) {
+            SPM_SET_ERR(ctx, "spm_hip_scan_segments: offsets must ascend and stay inside the text");
+            return SPM_E_INVALID;
+        }
+    spm_scan_opts o{};
+    if (opts_in)
+        o = *opts_in;
+    o.left_context = 0;
+    return scan_impl(ctx, text, seg_offsets[0], seg_offsets[n_segments], patterns, &o, nullptr, nullptr, seg_offsets,
+                     n_segments, out);
+}
+
+static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
+                     const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
+                     uint64_t n_segments, spm_hits **out)
 {
     if (!ctx || !text || !patterns || !out || begin > end || end > text->n) {
         SPM_SET_ERR(ctx, "spm_hip_scan: invalid argument");
@@ -1124,6 +1197,8 @@ extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, 
     SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
 
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
+    A.seg_offsets = seg_offsets;
+    A.n_segments = n_segments;
 
     const bool has_state = state_in != nullptr;
     const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && !patterns->fidx.empty());
@@ -1330,6 +1405,12 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
 {
     if (!h)
         return;
+    if (h->d_aux[0] || h->d_aux[1]) {
+        if (h->ctx)
+            hipStreamSynchronize(h->ctx->stream);
+        hipFree(h->d_aux[0]);
+        hipFree(h->d_aux[1]);
+    }
     if (h->ctx && h->d_hits && h->d_count && h->ev[3] && h->ctx->pool.size() < 8) {
         hits_block b;
         b.d_hits = h->d_hits;

@@ -210,6 +210,17 @@ def scan(ctx: Context, text: Text, pats: PatternSet, begin: int = 0, end: int | 
     return (hits, st_out) if want_state else hits
 
 
+def scan_segments(ctx: Context, text: Text, pats: PatternSet, seg_offsets, *, engine: int = capi.ENGINE_AUTO,
+                  max_hits: int = 0) -> Hits:
+    """Scan a batch of independent haystacks stored back to back (segment s = text[off[s]:off[s+1]]) in one launch."""
+    offs = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+    opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, sort=0, reserved=0)
+    h = C.c_void_p()
+    _check(capi.lib().spm_hip_scan_segments(ctx._h, text._h, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            len(offs) - 1, pats._h, C.byref(opts), C.byref(h)), ctx._h)
+    return Hits(ctx, h)
+
+
 def synth_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, kmax: int):
     out = np.empty(L, dtype=np.uint8)
     o = capi.lib().spm_hip_synth_pattern(seed_text, seed_pat, n_total, p, L, kmax,

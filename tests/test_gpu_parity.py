@@ -288,3 +288,50 @@ def test_filter_sub_batches_equal_single_pass(spm, ctx, oracle):
             want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
             assert len(want) >= 300
         assert np.array_equal(got, want), (max_keys, stride)
+
+
+@pytest.mark.parametrize("algo,L,k", [("myers", 100, 3), ("myers", 40, 2), ("shiftor", 32, 0), ("myers", 20, 1)])
+def test_segmented_haystacks_equal_per_segment_scans(spm, ctx, oracle, algo, L, k):
+    """spm_hip_scan_segments: many independent haystacks in one buffer, one launch == scanning each on its own.
+    Needles are planted inside segments AND across segment borders (those must NOT be reported)."""
+    rng = np.random.default_rng(L * 7 + k)
+    lens = [0, 5, 300, 17, 4096, 1, 999, 150, 0, 70000, 33, 2500]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(offs[-1])
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles = [rng.integers(0, 4, L, dtype=np.uint8) for _ in range(70)]
+    for i, nd in enumerate(needles):
+        s = [2, 4, 6, 9, 11][i % 5]
+        sb, se = int(offs[s]), int(offs[s + 1])
+        if se - sb > L + 4:
+            at = sb + int(rng.integers(0, se - sb - L - 2))
+            T[at:at + L] = nd
+        # straddle the border between segments 9 and 10
+        if i % 7 == 0:
+            b = int(offs[10])
+            T[b - L // 2:b - L // 2 + L] = nd
+    a = spm.ALGO_MYERS if algo == "myers" else spm.ALGO_SHIFTOR
+    text = ctx.upload(T)
+    ps = ctx.patterns(a, needles, k=k)
+    want = []
+    for s in range(len(lens)):
+        sb, se = int(offs[s]), int(offs[s + 1])
+        if se > sb:
+            v = spm.scan(ctx, text, ps, sb, se, engine=spm.ENGINE_BRUTE).view()  # haystack of its own
+            want.append(v)
+    want = np.sort(np.concatenate(want), order=["pattern", "pos"])
+    assert len(want) >= 30
+    engines = [spm.ENGINE_BRUTE] + ([spm.ENGINE_FILTER] if ps.filterable else [])
+    for engine in engines:
+        got = spm.scan_segments(ctx, text, ps, offs, engine=engine).view()
+        assert np.array_equal(got, want), engine
+    # oracle on two segments
+    for s in (4, 9):
+        sb, se = int(offs[s]), int(offs[s + 1])
+        o = _oracle_multi(oracle, algo, T[sb:se], needles[:8], [k] * 8)
+        g = [(p, pos - sb, sc) for p, pos, sc in _hits_list(want) if p < 8 and sb <= pos <= se and
+             (pos - (0 if algo == "myers" else 0)) >= sb]
+        if algo == "myers":
+            g = [(p, pos, sc) for p, pos, sc in g if 0 < pos <= se - sb]
+        # positions of other segments can alias only at the borders; compare as sets restricted to this segment
+        assert set(o) <= set(g)
