@@ -58,3 +58,29 @@ def gatherv_hits(local: torch.Tensor, dst: int = 0, group=None):
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)]):
             req.wait()
     return None
+
+
+def gather_hits_fused(buf: torch.Tensor, group=None):
+    """One-collective variant for the benchmark loop.  `buf` is an int64 tensor [cap + 1, 2]: row 0 holds the hit
+    count in column 0, rows 1..count the 16-byte records.  Every rank contributes the same fixed-size buffer to ONE
+    all-gather (ncclAllGather on RCCL); no count exchange, no host synchronisation on non-root ranks.  Returns the
+    [world, cap + 1, 2] tensor; use split_fused() on the root.  Counts above `cap` are detected there."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return buf.unsqueeze(0)
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(buf.cpu()) for _ in range(world)]
+        dist.all_gather(parts, buf.cpu().contiguous(), group=group)
+        return torch.stack(parts).to(buf.device)
+    out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    return out
+
+
+def split_fused(gathered: torch.Tensor) -> torch.Tensor:
+    """Root side of gather_hits_fused: concatenation of every rank's records in rank (= shard) order."""
+    cap = gathered.shape[1] - 1
+    counts = gathered[:, 0, 0].cpu().tolist()
+    if any(c > cap for c in counts):
+        raise OverflowError(f"a rank produced {max(counts)} hits but the fused gather buffer holds {cap}")
+    return torch.cat([gathered[r, 1:1 + int(c)] for r, c in enumerate(counts)]) if counts else gathered[0, 1:1]

@@ -23,7 +23,14 @@ def _worker(rank, world, port, counts, q):
         local[:, 0] = torch.arange(n) + 1000 * rank  # pos
         local[:, 1] = rank                            # pattern|score word
         out = sdist.gatherv_hits(local, dst=0)
+        # the one-collective variant used by bench.py must deliver the same records in the same order
+        cap = 16
+        buf = torch.zeros((cap + 1, 2), dtype=torch.int64)
+        buf[0, 0] = n
+        buf[1:1 + n] = local
+        fused = sdist.split_fused(sdist.gather_hits_fused(buf))
         if rank == 0:
+            assert torch.equal(fused, out)
             q.put(out.numpy().copy())
         else:
             assert out is None

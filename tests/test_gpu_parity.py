@@ -335,3 +335,48 @@ def test_segmented_haystacks_equal_per_segment_scans(spm, ctx, oracle, algo, L, 
             g = [(p, pos, sc) for p, pos, sc in g if 0 < pos <= se - sb]
         # positions of other segments can alias only at the borders; compare as sets restricted to this segment
         assert set(o) <= set(g)
+
+
+def test_filter_overflow_falls_back_to_brute_exactly(spm, ctx, oracle):
+    """Pathological input: a low-complexity text in which every sampled window is a seed match.  The candidate
+    buffer overflows, the host re-runs the scan with the brute engine; the result is still exact."""
+    n = 1 << 18
+    T = np.zeros(n, dtype=np.uint8)                    # AAAA...
+    T[5000:5100] = oracle.encode("ACGT" * 25)          # plus a little structure
+    needles = [np.zeros(100, np.uint8), np.zeros(64, np.uint8), oracle.encode("ACGT" * 25)]
+    needles[1][40] = 1
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=[3, 1, 3])
+    assert ps.filterable
+    os.environ["SPM_HIP_FILTER_CAND_CAP"] = "4096"
+    try:
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_AUTO, max_hits=1 << 22)
+        st = h.stats()
+        got = h.view()
+    finally:
+        del os.environ["SPM_HIP_FILTER_CAND_CAP"]
+    assert st.fell_back == 1 and st.engine_used == spm.ENGINE_BRUTE
+    want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view()
+    assert np.array_equal(got, want)
+    o = _oracle_multi(oracle, "myers", T, needles, [3, 1, 3])
+    assert _hits_list(got) == o
+    assert len(o) > 100000
+
+
+def test_filter_on_repetitive_text_without_overflow(spm, ctx, oracle):
+    """Tandem repeats: many true seed matches per needle, several seeds per occurrence (dedupe set), default caps."""
+    rng = np.random.default_rng(11)
+    unit = rng.integers(0, 4, 37, dtype=np.uint8)
+    T = np.tile(unit, 3000)
+    T[rng.integers(0, len(T), 400)] ^= 1               # sprinkle substitutions
+    needles = [np.tile(unit, 4)[i:i + 100].copy() for i in range(0, 37, 5)]
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_AUTO, max_hits=1 << 23)
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 23)
+    assert np.array_equal(hf.view(), hb.view())
+    assert len(hb.view()) > 10000
+    sub = [0, 3]
+    want = _oracle_multi(oracle, "myers", T, [needles[i] for i in sub], [3, 3])
+    got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub]
+    assert sorted(got) == want
