@@ -74,7 +74,8 @@ typedef struct spm_scan_opts {
                               whose last symbol lies in [begin,end) -- the shard rule of SURVEY.md 8(e). */
     uint64_t pos_offset;   /* added to every reported position (global coordinate of text[0]) */
     uint64_t max_hits;     /* capacity of the hit buffer; 0 = library default */
-    uint32_t sort;         /* 1: hits are returned sorted by (pattern, pos) -- callback order per matcher */
+    uint32_t reserved0;    /* must be 0.  (The host view spm_hip_hits_view is always sorted by (pattern, pos);
+                              the device view is in arrival order.) */
     uint32_t reserved;
 } spm_scan_opts;
 
@@ -149,7 +150,7 @@ int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const uint64_t *se
 /* ---- hits ------------------------------------------------------------------------------------------ */
 /* Host view, sorted by (pattern, pos): per pattern this is the order the reference's callback fires in. */
 int spm_hip_hits_view(spm_hits *hits, const spm_hit **records, uint64_t *n);
-/* Device view (unsorted unless opts.sort): pointer to n spm_hit records in HBM, for an RCCL gatherv. */
+/* Device view (arrival order, not sorted): pointer to n spm_hit records in HBM, for an RCCL gather. */
 int spm_hip_hits_device(spm_hits *hits, const void **device_records, uint64_t *n);
 /* Copy the first min(n, cap) records into a caller-owned device buffer (e.g. a torch tensor that an RCCL
  * send/recv will read), asynchronously on the context's stream.  *n receives the number of hits. */

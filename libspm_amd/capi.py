@@ -31,7 +31,7 @@ class ScanOpts(C.Structure):
         ("left_context", C.c_uint32),
         ("pos_offset", C.c_uint64),
         ("max_hits", C.c_uint64),
-        ("sort", C.c_uint32),
+        ("reserved0", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
 

@@ -135,6 +135,24 @@ __device__ __forceinline__ uint32_t pack16(const uint4 v)
     return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
 }
 
+// dna5 haystacks (seqan3 ranks A0 C1 G2 N3 T4): same 2-bit word with T folded onto 3, plus a 16-bit mask of the N
+// positions; a window that contains an N cannot equal any (N-free) key and is dropped.  ~7 VALU per dword.
+__device__ __forceinline__ uint32_t pack16_dna5(const uint4 v, uint32_t &nmask)
+{
+    const uint32_t W = 0x40100401u, WN = 0x08040201u;
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t code = 0;
+    nmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t isT = (x[i] >> 2) & 0x01010101u;            // byte == 4
+        const uint32_t isN = x[i] & (x[i] >> 1) & 0x01010101u;     // byte == 3
+        code |= __builtin_amdgcn_udot4(x[i] - isT, W, 0u, false) << (8 * i);
+        nmask |= __builtin_amdgcn_udot4(isN, WN, 0u, false) << (4 * i);
+    }
+    return code;
+}
+
 __device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, uint64_t limit)
 {
     // idx % 16 == 0.  Bytes at or beyond `limit` read as 0.
@@ -166,21 +184,30 @@ __device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
 
 // One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
 // gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
-template <int S, int UU, int HV>
+template <int S, int UU, int HV, int SIG>
 __device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
-                                             uint32_t &carry_in, uint32_t lane, const uint32_t *lds,
-                                             uint32_t idx_mask)
+                                             uint32_t &carry_in, uint32_t &carry_n, uint32_t lane,
+                                             const uint32_t *lds, uint32_t idx_mask)
 {
     constexpr int NWIN = 16 / S; // windows per lane per chunk
     static_assert(UU * NWIN <= 32, "one mask bit per window of a group");
     uint32_t w[UU], prev[UU];
+    uint32_t nv[SIG == 5 ? UU : 1]; // dna5: (this lane's N mask << 16) | previous lane's N mask
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
-        w[u] = pack16(cur[u]);
+        uint32_t nm = 0;
+        w[u] = SIG == 5 ? pack16_dna5(cur[u], nm) : pack16(cur[u]);
         prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
         if (lane == 0)
             prev[u] = carry_in;
         carry_in = __builtin_amdgcn_readlane(w[u], 63);
+        if (SIG == 5) {
+            uint32_t np = __builtin_amdgcn_update_dpp(0u, nm, 0x138, 0xF, 0xF, false);
+            if (lane == 0)
+                np = carry_n;
+            carry_n = __builtin_amdgcn_readlane(nm, 63);
+            nv[u] = (nm << 16) | np;
+        }
     }
     // windows d = S, 2S, .., 16 of chunk u: text start t = L_u - 16 + d, key = bits [2d, 2d+32) of (w:prev)
     uint32_t pos_mask = 0;
@@ -255,6 +282,19 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             pos_mask = keep;
         }
     }
+    if constexpr (SIG == 5) {
+        if (__ballot(pos_mask != 0) != 0) {
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+#pragma unroll
+                for (int i = 0; i < NWIN; ++i) {
+                    const int d = S * (i + 1);
+                    if (__builtin_amdgcn_ubfe(nv[u], d, 16) != 0) // an N inside the window
+                        pos_mask &= ~(1u << (u * NWIN + i));
+                }
+            }
+        }
+    }
     // survivors: exact key table
     while (__ballot(pos_mask != 0) != 0) {
         bool emit = false;
@@ -324,7 +364,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
 // (U KiB contiguous per wave) while the unconditional 16-byte loads of the next group are already in flight, so
 // each wave keeps 2*U KiB outstanding.  Only groups that lie fully inside the text take this path; the ragged end
 // of the text goes through a guarded one-chunk loop (bytes past the end read as 0).
-template <int S, int U, bool NT, int HV>
+template <int S, int U, bool NT, int HV, int SIG>
 __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
@@ -383,12 +423,15 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
         const uint64_t c_begin = sp * span;
         const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
         // word of the lane "before lane 0": last 16 bytes of the previous chunk
-        uint32_t carry_in = 0;
+        uint32_t carry_in = 0, carry_n = 0;
         {
             const uint64_t cb = base0 + c_begin * 1024;
-            if (cb >= 16 && lane == 0)
-                carry_in = pack16(load_text16(P.text, cb - 16, P.hi));
+            if (cb >= 16 && lane == 0) {
+                const uint4 before = load_text16(P.text, cb - 16, P.hi);
+                carry_in = SIG == 5 ? pack16_dna5(before, carry_n) : pack16(before);
+            }
             carry_in = __builtin_amdgcn_readfirstlane(carry_in);
+            carry_n = __builtin_amdgcn_readfirstlane(carry_n);
         }
         // ---- fast path: whole groups ----
         uint64_t ch = c_begin;
@@ -412,14 +455,14 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     nxt[u] = load16_stream<NT>(lane_text + pf * 1024 + (uint64_t)u * ustride);
-                filter_group<S, U, HV>(P, cur, base0 + ch * 1024, carry_in, lane, lds, idx_mask);
+                filter_group<S, U, HV, SIG>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
             }
         }
         // ---- ragged end ----
         for (; ch < c_end; ++ch) {
             uint4 one[1];
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
-            filter_group<S, 1, HV>(P, one, base0 + ch * 1024, carry_in, lane, lds, idx_mask);
+            filter_group<S, 1, HV, SIG>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
         }
         sp += n_waves;
     }
@@ -439,7 +482,9 @@ struct verify_params
     const candidate *cand;
     const unsigned long long *counters; // [1] candidates
     uint64_t cand_cap;
-    const uint64_t *peq64; // [pattern][4][NB] unshifted 64-bit Peq words
+    const uint64_t *peq64; // [pattern][sigma][NB] unshifted 64-bit Peq words
+    uint32_t sigma;        // alphabet size; LDS holds sigma+1 rows per thread (row sigma = no match)
+    uint32_t pad2;
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
@@ -460,7 +505,7 @@ struct verify_params
 template <int NB>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
-    extern __shared__ uint64_t vlds[]; // [4][NB][blockDim.x]
+    extern __shared__ uint64_t vlds[]; // [sigma + 1][NB][blockDim.x]
     const uint32_t tid = threadIdx.x;
     const uint32_t nthr = blockDim.x;
     unsigned long long n_cand = P.counters[1];
@@ -507,10 +552,12 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         if (ws < hay_b)
             ws = hay_b;
         // stage this needle's Peq rows
-        const uint64_t *peq = P.peq64 + (size_t)pat * 4 * NB;
-#pragma unroll
-        for (int i = 0; i < 4 * NB; ++i)
+        const uint64_t *peq = P.peq64 + (size_t)pat * P.sigma * NB;
+        for (uint32_t i = 0; i < P.sigma * NB; ++i)
             vlds[(size_t)i * nthr + tid] = peq[i];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            vlds[((size_t)P.sigma * NB + b) * nthr + tid] = 0; // symbols outside the alphabet match nothing
         uint64_t VP[NB], VN[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -533,7 +580,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                 const int64_t p = blk + i;
                 if (p < ws || p >= e_hi)
                     continue;
-                const uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 3;
+                uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                sym = sym < P.sigma ? sym : P.sigma;
                 const uint64_t *row = vlds + ((size_t)sym * NB) * nthr + tid;
                 uint64_t carry = 0, hp_c = 0, hn_c = 0;
                 uint64_t HPl = 0, HNl = 0;

@@ -88,8 +88,12 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
     ps->fidx.clear();
-    if (ps->sigma != 4 || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 || ps->n >= (1u << 21))
+    if ((ps->sigma != 4 && ps->sigma != 5) || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 || ps->n >= (1u << 21))
         return SPM_OK;
+    if (ps->sigma == 5) // dna5: the 2-bit keys cannot hold an N (rank 3); needles with an N go to the brute engine
+        for (uint8_t c : ps->ranks)
+            if (c == 3)
+                return SPM_OK;
     uint32_t qmin = 0xFFFFFFFFu;
     uint64_t n_seeds = 0;
     for (uint32_t p = 0; p < ps->n; ++p) {
@@ -181,7 +185,7 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
                 // window seed[r, r+16) -- inside the seed because S <= q - 15
                 uint32_t key = 0;
                 for (uint32_t i = 0; i < kKeyH; ++i)
-                    key |= (uint32_t)(pat[o + r + i] & 3) << (2 * i);
+                    key |= (uint32_t)((ps->sigma == 5 && pat[o + r + i] == 4) ? 3u : (pat[o + r + i] & 3u)) << (2 * i);
                 keys.push_back({key, (p << 11) | (o + r)});
             }
         }
@@ -265,6 +269,8 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
             F.hash_variant = 1; // key set too dense for the fingerprint table: Bloom cascade
         }
     }
+    if (ps->sigma == 5 && F.hash_variant != 2)
+        return SPM_OK; // the dna5 kernel is built for the fingerprint table only
     if (F.hash_variant != 2) {
         uint64_t want_bits = F.n_keys * 32;
         uint32_t words = 1024;
@@ -408,14 +414,14 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 
     // ---- filter engine tables ----
-    if (sigma == 4 && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
+    if ((sigma == 4 || sigma == 5) && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
         const uint32_t NB = ps->NB64;
-        std::vector<uint64_t> p64((size_t)n_patterns * 4 * NB, 0);
+        std::vector<uint64_t> p64((size_t)n_patterns * sigma * NB, 0);
         for (uint32_t p = 0; p < n_patterns; ++p)
             for (uint32_t j = 0; j < (uint32_t)ps->m[p]; ++j) {
                 const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                if (c < 4)
-                    p64[((size_t)p * 4 + c) * NB + j / 64] |= 1ull << (j % 64);
+                if (c < sigma)
+                    p64[((size_t)p * sigma + c) * NB + j / 64] |= 1ull << (j % 64);
             }
         SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq64, p64.size() * sizeof(uint64_t)));
         SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq64, p64.data(), p64.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -825,8 +831,8 @@ template <int NB>
 void launch_verify_nb(const verify_params &V, dim3 grid, hipStream_t s)
 {
     // LDS holds 4*NB uint64 per thread; keep the block within 128 KiB
-    const uint32_t threads = NB <= 16 ? 256u : 128u;
-    const size_t lds = (size_t)4 * NB * 8 * threads;
+    const uint32_t threads = NB <= 8 ? 256u : (NB <= 16 ? 128u : 64u);
+    const size_t lds = (size_t)(V.sigma + 1) * NB * 8 * threads;
     hipFuncSetAttribute((const void *)verify_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_kernel<NB>), grid, dim3(threads), lds, s, V);
 }
@@ -1038,9 +1044,17 @@ int run_filter(const scan_args &A)
     P.hash_variant = F.hash_variant;
 #define LAUNCH_FILTER3(S, UU, NTT, HV)                                                                                 \
     do {                                                                                                               \
-        hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV>,                                          \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-        hipLaunchKernelGGL((seed_filter_kernel<S, UU, NTT, HV>), dim3(grid), dim3(threads), lds, ctx->stream, P);      \
+        if (ps->sigma == 5) {                                                                                          \
+            hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, true, 2, 5>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+            hipLaunchKernelGGL((seed_filter_kernel<S, UU, true, 2, 5>), dim3(grid), dim3(threads), lds, ctx->stream,   \
+                               P);                                                                                     \
+        } else {                                                                                                       \
+            hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV, 4>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+            hipLaunchKernelGGL((seed_filter_kernel<S, UU, NTT, HV, 4>), dim3(grid), dim3(threads), lds, ctx->stream,   \
+                               P);                                                                                     \
+        }                                                                                                              \
     } while (0)
 #define LAUNCH_FILTER2(S, UU)                                                                                          \
     do {                                                                                                               \
@@ -1093,6 +1107,7 @@ int run_filter(const scan_args &A)
     V.counters = H->d_count;
     V.cand_cap = cand_cap;
     V.peq64 = ps->d_peq64;
+    V.sigma = ps->sigma;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;

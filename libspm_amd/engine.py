@@ -198,7 +198,7 @@ def scan(ctx: Context, text: Text, pats: PatternSet, begin: int = 0, end: int | 
     Returns Hits, or (Hits, state_out) when want_state is set."""
     end = len(text) if end is None else end
     opts = capi.ScanOpts(engine=engine, left_context=1 if left_context else 0, pos_offset=pos_offset,
-                         max_hits=max_hits, sort=0, reserved=0)
+                         max_hits=max_hits, reserved0=0, reserved=0)
     h = C.c_void_p()
     st_in = state_in.ctypes.data if state_in is not None else None
     st_out = None
@@ -214,7 +214,7 @@ def scan_segments(ctx: Context, text: Text, pats: PatternSet, seg_offsets, *, en
                   max_hits: int = 0) -> Hits:
     """Scan a batch of independent haystacks stored back to back (segment s = text[off[s]:off[s+1]]) in one launch."""
     offs = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
-    opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, sort=0, reserved=0)
+    opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, reserved0=0, reserved=0)
     h = C.c_void_p()
     _check(capi.lib().spm_hip_scan_segments(ctx._h, text._h, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                                             len(offs) - 1, pats._h, C.byref(opts), C.byref(h)), ctx._h)

@@ -380,3 +380,99 @@ def test_filter_on_repetitive_text_without_overflow(spm, ctx, oracle):
     want = _oracle_multi(oracle, "myers", T, [needles[i] for i in sub], [3, 3])
     got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub]
     assert sorted(got) == want
+
+
+def test_fuzz_engines_against_oracle(spm, ctx, oracle):
+    """Randomised configurations (needle length, k, set size, alphabet, text length, sub-ranges): brute engine ==
+    oracle always; filter engine == brute whenever the set admits it."""
+    rng = np.random.default_rng(20260104)
+    n_filter = 0
+    for it in range(60):
+        sigma = int(rng.choice([4, 4, 4, 5, 15]))
+        m = int(rng.choice([1, 3, 8, 17, 32, 33, 50, 64, 65, 90, 100, 128, 160, 257]))
+        k = int(rng.integers(0, min(m, 6)))
+        n = int(rng.choice([0, 1, 7, 255, 256, 257, 1023, 4097, 20011]))
+        n_needles = int(rng.choice([1, 2, 63, 64, 65, 130]))
+        algo = "myers" if it % 3 else "shiftor"
+        T = rng.integers(0, sigma, n, dtype=np.uint8)
+        needles, ks = [], []
+        for i in range(n_needles):
+            mm = max(1, m - int(rng.integers(0, 3)))
+            nd = rng.integers(0, sigma, mm, dtype=np.uint8)
+            if n > 2 * mm + 2 and i % 2 == 0:
+                at = int(rng.integers(0, n - mm))
+                occ = nd.copy()
+                if k and mm > 3 and i % 4 == 0:
+                    occ[mm // 2] = (occ[mm // 2] + 1) % sigma
+                T[at:at + mm] = occ
+            needles.append(nd)
+            ks.append(min(k, mm - 1))
+        a = spm.ALGO_MYERS if algo == "myers" else spm.ALGO_SHIFTOR
+        text = ctx.upload(T, sigma=sigma)
+        ps = ctx.patterns(a, needles, k=ks if algo == "myers" else 0, sigma=sigma)
+        lo = int(rng.integers(0, n + 1)) if it % 5 == 0 else 0
+        hi = int(rng.integers(lo, n + 1)) if it % 5 == 0 else n
+        got = _hits_list(spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view())
+        sub = list(range(0, n_needles, max(1, n_needles // 6)))
+        want = []
+        for j, p in enumerate(sub):
+            nd = needles[p]
+            if algo == "myers":
+                r = oracle.myers(T[lo:hi], nd, ks[p], sigma=sigma)
+                want += [(p, int(x) + lo, int(s)) for x, s in zip(r["pos"], r["score"])]
+            else:
+                want += [(p, int(x) + lo, 0) for x in oracle.shiftor(T[lo:hi], nd, sigma)]
+        assert sorted(x for x in got if x[0] in sub) == sorted(want), (it, sigma, m, k, n, n_needles, algo, lo, hi)
+        if ps.filterable and hi > lo:
+            n_filter += 1
+            gf = _hits_list(spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, max_hits=1 << 22).view())
+            assert gf == got, (it, "filter", sigma, m, k, n, n_needles, algo, lo, hi)
+    assert n_filter >= 5
+
+
+def test_dna5_haystack_through_the_seed_filter(spm, ctx, oracle):
+    """dna5 text (ranks A0 C1 G2 N3 T4) with runs of N and isolated Ns: the seed filter drops windows containing an
+    N, verification runs on 5 Peq rows.  filter == brute == oracle.  Needles with an N are not filterable."""
+    rng = np.random.default_rng(55)
+    n = 1 << 20
+    T = rng.choice(np.array([0, 1, 2, 4], dtype=np.uint8), n)
+    for at in rng.integers(0, n - 3000, 40):
+        T[at:at + int(rng.integers(1, 2000))] = 3          # N runs (assembly gaps)
+    T[rng.integers(0, n, 2000)] = 3                          # isolated Ns
+    needles = []
+    for i in range(96):
+        at = int(rng.integers(0, n - 400))
+        nd = T[at:at + 100].copy()
+        nd[nd == 3] = 0                                      # needles are N-free
+        if i % 3 == 1:
+            nd[50] = [0, 1, 2, 4][(int(nd[50]) + 1) % 4 if nd[50] < 3 else 0]
+        if i % 3 == 2:
+            nd = np.delete(nd, 30)
+        needles.append(nd)
+        if i % 4 == 0:                                       # plant a clean copy next to an N so windows straddle it
+            p = int(rng.integers(0, n - 300))
+            T[p:p + len(nd)] = nd
+            T[p - 1] = 3
+    text = ctx.upload(T, sigma=5)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3, sigma=5)
+    assert ps.filterable
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
+    assert hf.stats().engine_used == spm.ENGINE_FILTER and hf.stats().fell_back == 0
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE)
+    assert np.array_equal(hf.view(), hb.view())
+    assert len(hb.view()) >= 96
+    sub = list(range(0, 96, 12))
+    want = []
+    for j, p in enumerate(sub):
+        r = oracle.myers(T, needles[p], 3, sigma=5)
+        want += [(j, int(x), int(s)) for x, s in zip(r["pos"], r["score"])]
+    got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub]
+    assert sorted(got) == sorted(want)
+    with_n = [nd.copy() for nd in needles[:4]]
+    with_n[0][10] = 3
+    assert not ctx.patterns(spm.ALGO_MYERS, with_n, k=3, sigma=5).filterable
+    # exact matcher on dna5
+    pe = ctx.patterns(spm.ALGO_SHIFTOR, [nd[:40] for nd in needles[:64]], sigma=5)
+    assert pe.filterable
+    assert np.array_equal(spm.scan(ctx, text, pe, engine=spm.ENGINE_FILTER).view(),
+                          spm.scan(ctx, text, pe, engine=spm.ENGINE_BRUTE).view())
