@@ -74,10 +74,12 @@ typedef struct spm_scan_opts {
                               whose last symbol lies in [begin,end) -- the shard rule of SURVEY.md 8(e). */
     uint64_t pos_offset;   /* added to every reported position (global coordinate of text[0]) */
     uint64_t max_hits;     /* capacity of the hit buffer; 0 = library default */
-    uint32_t reserved0;    /* must be 0.  (The host view spm_hip_hits_view is always sorted by (pattern, pos);
+    uint32_t flags;        /* SPM_SCAN_* bits.  (The host view spm_hip_hits_view is always sorted by (pattern, pos);
                               the device view is in arrival order.) */
     uint32_t reserved;
 } spm_scan_opts;
+
+#define SPM_SCAN_IGNORE_PACKED 1u /* do not use the text's 2-bit shadow even if it has one */
 
 /* Per-scan device timings, HIP events on the context's stream (ms). */
 typedef struct spm_scan_stats {
@@ -106,6 +108,13 @@ int spm_hip_text_upload(spm_ctx *ctx, const uint8_t *ranks, uint64_t n, uint32_t
 int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_t n, uint32_t sigma, spm_text **out);
 /* Synthetic uniform dna4 text generated in HBM: base(i) of SURVEY.md 8(d) for i in [global_begin, +n). */
 int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, spm_text **out);
+/* Optional: build a 2-bit shadow of a dna4 haystack (16 symbols per uint32, +25 % HBM).  Later seed-filter scans of
+ * this text stream the shadow instead of the 1-byte ranks -- a quarter of the HBM traffic -- and return identical hits;
+ * verification and the brute-force engine keep reading the original ranks.  Meant for a reference that is scanned
+ * against many needle batches.  SPM_E_INVALID if the text holds a symbol >= 4 or is not dna4.
+ * spm_scan_opts.flags & SPM_SCAN_IGNORE_PACKED makes a scan read the 1-byte text anyway. */
+int spm_hip_text_pack(spm_ctx *ctx, spm_text *text);
+int spm_hip_text_is_packed(const spm_text *text);
 int spm_hip_text_download(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t n, uint8_t *out);
 uint64_t spm_hip_text_length(const spm_text *text);
 const void *spm_hip_text_device_ptr(const spm_text *text);

@@ -14,6 +14,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 ALGO_SHIFTOR, ALGO_MYERS, ALGO_MYERS_PREFIX, ALGO_HORSPOOL = 0, 1, 2, 3
 ENGINE_AUTO, ENGINE_BRUTE, ENGINE_FILTER = 0, 1, 2
+SCAN_IGNORE_PACKED = 1
 MAX_NEEDLE = 2048
 
 
@@ -31,7 +32,7 @@ class ScanOpts(C.Structure):
         ("left_context", C.c_uint32),
         ("pos_offset", C.c_uint64),
         ("max_hits", C.c_uint64),
-        ("reserved0", C.c_uint32),
+        ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
 
@@ -81,6 +82,8 @@ def lib():
         "spm_hip_text_upload": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
         "spm_hip_text_wrap": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
         "spm_hip_text_generate": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+        "spm_hip_text_pack": (C.c_int, [vp, vp]),
+        "spm_hip_text_is_packed": (C.c_int, [vp]),
         "spm_hip_text_download": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
         "spm_hip_text_length": (C.c_uint64, [vp]),
         "spm_hip_text_device_ptr": (vp, [vp]),
@@ -115,7 +118,8 @@ def lib():
 
 EXPORTS = [
     "spm_hip_init", "spm_hip_destroy", "spm_hip_last_error", "spm_hip_synchronize", "spm_hip_text_upload",
-    "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_download", "spm_hip_text_length",
+    "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_pack", "spm_hip_text_is_packed",
+    "spm_hip_text_download", "spm_hip_text_length",
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",

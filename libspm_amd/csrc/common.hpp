@@ -53,6 +53,8 @@ struct spm_text
     uint64_t alloc = 0; // bytes readable from d (>= n)
     uint32_t sigma = 4;
     bool owned = false;
+    uint32_t *d_packed = nullptr; // optional 2-bit shadow (spm_hip_text_pack), zero-padded to whole 4096-symbol chunks
+    uint64_t packed_words = 0;
 };
 
 struct spm_hits

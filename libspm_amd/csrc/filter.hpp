@@ -165,10 +165,6 @@ __device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
-// (U KiB contiguous per wave) while the 16-byte loads of the next group are already in flight, so that each wave
-// keeps 2*U KiB outstanding -- the filter is bound by bytes in flight, not by issue (20-40 VGPRs, ~100 wave
-// instructions per KiB).
 template <bool NT>
 __device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
 {
@@ -182,33 +178,15 @@ __device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
     return *reinterpret_cast<const uint4 *>(p);
 }
 
-// One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
-// gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
-template <int S, int UU, int HV, int SIG>
-__device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
-                                             uint32_t &carry_in, uint32_t &carry_n, uint32_t lane,
-                                             const uint32_t *lds, uint32_t idx_mask)
+// Level 1 + level 2 on NWD 2-bit-packed words per lane (w[j] = 16 bases, prev[j] = the 16 bases before them).
+// PK selects how word j maps to a text position (1-byte text vs. packed shadow).
+template <int S, int NWD, int HV, int SIG, bool PK>
+__device__ __forceinline__ void filter_words(const filter_params &P, const uint32_t (&w)[NWD],
+                                             const uint32_t (&prev)[NWD], const uint32_t (&nv)[SIG == 5 ? NWD : 1],
+                                             uint64_t gbase, uint32_t lane, const uint32_t *lds, uint32_t idx_mask)
 {
-    constexpr int NWIN = 16 / S; // windows per lane per chunk
-    static_assert(UU * NWIN <= 32, "one mask bit per window of a group");
-    uint32_t w[UU], prev[UU];
-    uint32_t nv[SIG == 5 ? UU : 1]; // dna5: (this lane's N mask << 16) | previous lane's N mask
-#pragma unroll
-    for (int u = 0; u < UU; ++u) {
-        uint32_t nm = 0;
-        w[u] = SIG == 5 ? pack16_dna5(cur[u], nm) : pack16(cur[u]);
-        prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
-        if (lane == 0)
-            prev[u] = carry_in;
-        carry_in = __builtin_amdgcn_readlane(w[u], 63);
-        if (SIG == 5) {
-            uint32_t np = __builtin_amdgcn_update_dpp(0u, nm, 0x138, 0xF, 0xF, false);
-            if (lane == 0)
-                np = carry_n;
-            carry_n = __builtin_amdgcn_readlane(nm, 63);
-            nv[u] = (nm << 16) | np;
-        }
-    }
+    constexpr int NWIN = 16 / S; // windows per word
+    static_assert(NWD * NWIN <= 32, "one mask bit per window of a group");
     // windows d = S, 2S, .., 16 of chunk u: text start t = L_u - 16 + d, key = bits [2d, 2d+32) of (w:prev)
     uint32_t pos_mask = 0;
     if constexpr (HV == 2) {
@@ -216,9 +194,9 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
         // fingerprint at the displaced slot -- two LDS round trips per group, all windows in flight together
         const uint16_t *fp_tab = reinterpret_cast<const uint16_t *>(lds);
         const uint16_t *disp_tab = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(lds) + P.chd_disp_off);
-        uint32_t xs[UU * NWIN], ds[UU * NWIN];
+        uint32_t xs[NWD * NWIN], ds[NWD * NWIN];
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
+        for (int u = 0; u < NWD; ++u) {
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
@@ -229,7 +207,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             }
         }
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
+        for (int u = 0; u < NWD; ++u) {
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
@@ -240,7 +218,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             }
         }
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
+        for (int u = 0; u < NWD; ++u) {
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
@@ -251,7 +229,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
+        for (int u = 0; u < NWD; ++u) {
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
@@ -267,7 +245,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
                 break;
             uint32_t keep = 0;
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
+            for (int u = 0; u < NWD; ++u) {
 #pragma unroll
                 for (int i = 0; i < NWIN; ++i) {
                     if (pos_mask & (1u << (u * NWIN + i))) {
@@ -285,7 +263,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
     if constexpr (SIG == 5) {
         if (__ballot(pos_mask != 0) != 0) {
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
+            for (int u = 0; u < NWD; ++u) {
 #pragma unroll
                 for (int i = 0; i < NWIN; ++i) {
                     const int d = S * (i + 1);
@@ -310,13 +288,17 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             const int d = S * (i + 1);
             uint32_t wu = w[0], pu = prev[0];
 #pragma unroll
-            for (int q = 1; q < UU; ++q)
+            for (int q = 1; q < NWD; ++q)
                 if (u == q) {
                     wu = w[q];
                     pu = prev[q];
                 }
             key = d == 16 ? wu : alignbit(wu, pu, (uint32_t)(2 * d) & 31u);
-            const int64_t ts = (int64_t)(gbase + (uint64_t)u * 1024 + (uint64_t)lane * 16) - 16 + d;
+            // first base of word u of this lane: 1-byte text = chunk u, 16 bytes per lane; packed shadow = load u>>2
+            // (4096 bases), 64 bases per lane, word u&3
+            const uint64_t wpos = PK ? gbase + (uint64_t)(u >> 2) * 4096 + (uint64_t)lane * 64 + (uint64_t)(u & 3) * 16
+                                     : gbase + (uint64_t)u * 1024 + (uint64_t)lane * 16;
+            const int64_t ts = (int64_t)wpos - 16 + d;
             if (ts >= (int64_t)P.lo && (uint64_t)ts + kKeyH <= P.hi) {
                 t = (uint64_t)ts;
                 slot = ht_hash(key) & P.ht_mask;
@@ -358,6 +340,35 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             }
         }
     }
+}
+
+
+// One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
+// gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
+template <int S, int UU, int HV, int SIG>
+__device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
+                                             uint32_t &carry_in, uint32_t &carry_n, uint32_t lane,
+                                             const uint32_t *lds, uint32_t idx_mask)
+{
+    uint32_t w[UU], prev[UU];
+    uint32_t nv[SIG == 5 ? UU : 1]; // dna5: (this lane's N mask << 16) | previous lane's N mask
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        uint32_t nm = 0;
+        w[u] = SIG == 5 ? pack16_dna5(cur[u], nm) : pack16(cur[u]);
+        prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+        if (lane == 0)
+            prev[u] = carry_in;
+        carry_in = __builtin_amdgcn_readlane(w[u], 63);
+        if (SIG == 5) {
+            uint32_t np = __builtin_amdgcn_update_dpp(0u, nm, 0x138, 0xF, 0xF, false);
+            if (lane == 0)
+                np = carry_n;
+            carry_n = __builtin_amdgcn_readlane(nm, 63);
+            nv[u] = (nm << 16) | np;
+        }
+    }
+    filter_words<S, UU, HV, SIG, false>(P, w, prev, nv, gbase, lane, lds, idx_mask);
 }
 
 // Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
@@ -463,6 +474,126 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
             uint4 one[1];
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
             filter_group<S, 1, HV, SIG>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
+        }
+        sp += n_waves;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Optional 2-bit shadow of a dna4 haystack (spm_hip_text_pack): 16 symbols per uint32, same bit order as pack16.
+// A text that is scanned many times (one reference, many needle batches) is then streamed at a quarter of the
+// HBM traffic; hits are identical.  text_pack_kernel builds it in one pass and flags symbols outside {0..3}.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_pack_kernel(const uint8_t *__restrict__ text, uint64_t n,
+                                                        uint32_t *__restrict__ packed, uint64_t n_words,
+                                                        unsigned int *bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned int any_bad = 0;
+    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += stride) {
+        const uint4 v = load_text16(text, wi * 16, n);
+        any_bad |= (v.x | v.y | v.z | v.w) & 0xFCFCFCFCu;
+        packed[wi] = pack16(v);
+    }
+    if (any_bad)
+        atomicOr(bad, 1u);
+}
+
+// Same filter, fed from the shadow: one 16-byte load per lane = 4 words = 64 symbols; a wave-load ("p-chunk") covers
+// 4096 symbols.  U2 p-chunks per group, the next group's loads in flight.  The shadow is zero-padded to whole
+// p-chunks, so every load is unconditional; windows reaching past the text are dropped by the range check.
+template <int S, int U2, int HV>
+__global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_params P, const uint4 *__restrict__ shadow)
+{
+    extern __shared__ uint32_t lds[];
+    for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
+        lds[i] = P.bitmap[i];
+    __syncthreads();
+
+    constexpr int NWD = 4 * U2;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+    const uint32_t idx_mask = P.bitmap_words * 32 - 1;
+
+    const uint64_t base0 = P.lo & ~4095ull;                   // p-chunks are aligned to 4096 symbols
+    const uint64_t n_chunks = (P.hi - base0 + 4095) / 4096;
+    const uint64_t span = P.span_chunks;                      // multiple of U2
+    const uint64_t n_spans = (n_chunks + span - 1) / span;
+    const uint4 *lane_src = shadow + (base0 / 64) + lane;     // one uint4 = 64 symbols
+
+    uint64_t sp = wave_id;
+    for (;;) {
+        if (P.dynamic == 1) {
+            unsigned long long t = 0;
+            if (lane == 0)
+                t = atomicAdd(&P.counters[4], 1ull);
+            sp = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+        } else if (P.dynamic == 2) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned long long t = atomicAdd(&P.counters[4], (unsigned long long)waves_per_wg);
+                lds[P.lds_words] = (uint32_t)t;
+                lds[P.lds_words + 1] = (uint32_t)(t >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lds[P.lds_words + 1]) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane(lds[P.lds_words]);
+            if (base >= n_spans)
+                break;
+            sp = base + wave_in_wg;
+            if (sp >= n_spans)
+                continue;
+        }
+        if (sp >= n_spans)
+            break;
+        const uint64_t c_begin = sp * span;
+        const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
+        const uint64_t fast_end = c_begin + (c_end - c_begin + U2 - 1) / U2 * U2; // whole groups (shadow is padded)
+        // the word in front of this span's first word
+        uint32_t carry_in = 0;
+        {
+            const uint64_t first_word = (base0 + c_begin * 4096) / 16;
+            if (first_word > 0 && lane == 0)
+                carry_in = reinterpret_cast<const uint32_t *>(shadow)[first_word - 1];
+            carry_in = __builtin_amdgcn_readfirstlane(carry_in);
+        }
+        uint4 nxt[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u)
+            nxt[u] = load16_stream<true>(reinterpret_cast<const uint8_t *>(lane_src + (c_begin + u) * 64));
+        for (uint64_t ch = c_begin; ch < fast_end; ch += U2) {
+            uint4 cur[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u)
+                cur[u] = nxt[u];
+            const bool more = ch + U2 < fast_end;
+            const uint64_t pf = more ? ch + U2 : ch;
+            const uint64_t ustride = more ? 64 : 0;
+#pragma unroll
+            for (int u = 0; u < U2; ++u)
+                nxt[u] = load16_stream<true>(reinterpret_cast<const uint8_t *>(lane_src + pf * 64 + (uint64_t)u * ustride));
+            uint32_t w[NWD], prev[NWD];
+            const uint32_t nv[1] = {0};
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                w[4 * u + 0] = cur[u].x;
+                w[4 * u + 1] = cur[u].y;
+                w[4 * u + 2] = cur[u].z;
+                w[4 * u + 3] = cur[u].w;
+                uint32_t p0 = __builtin_amdgcn_update_dpp(0u, cur[u].w, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+                if (lane == 0)
+                    p0 = carry_in;
+                carry_in = __builtin_amdgcn_readlane(cur[u].w, 63);
+                prev[4 * u + 0] = p0;
+                prev[4 * u + 1] = cur[u].x;
+                prev[4 * u + 2] = cur[u].y;
+                prev[4 * u + 3] = cur[u].z;
+            }
+            filter_words<S, NWD, HV, 4, true>(P, w, prev, nv, base0 + ch * 4096, lane, lds, idx_mask);
         }
         sp += n_waves;
     }

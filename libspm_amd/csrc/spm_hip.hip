@@ -745,6 +745,49 @@ extern "C" int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t globa
     return SPM_OK;
 }
 
+extern "C" int spm_hip_text_pack(spm_ctx *ctx, spm_text *text)
+{
+    if (!ctx || !text) {
+        SPM_SET_ERR(ctx, "spm_hip_text_pack: invalid argument");
+        return SPM_E_INVALID;
+    }
+    if (text->sigma != 4) {
+        SPM_SET_ERR(ctx, "spm_hip_text_pack: only dna4 haystacks have a 2-bit encoding (sigma = %u)", text->sigma);
+        return SPM_E_INVALID;
+    }
+    if (text->d_packed)
+        return SPM_OK;
+    SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_words = (text->n + 15) / 16;
+    const uint64_t padded = ((text->n + 4095) / 4096) * 256 + 2048; // whole p-chunks + one group of slack
+    uint32_t *d = nullptr;
+    unsigned int *d_bad = nullptr;
+    SPM_HIP_CHECK(ctx, hipMalloc(&d, padded * sizeof(uint32_t)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&d_bad, sizeof(unsigned int)));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(d, 0, padded * sizeof(uint32_t), ctx->stream));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(d_bad, 0, sizeof(unsigned int), ctx->stream));
+    if (n_words) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_words + 255) / 256, (uint64_t)ctx->n_cu * 16);
+        hipLaunchKernelGGL(text_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, text->d,
+                           text->owned ? std::min(text->alloc, text->n) : text->n, d, n_words, d_bad);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    unsigned int bad = 0;
+    SPM_HIP_CHECK(ctx, hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_bad);
+    if (bad) {
+        hipFree(d);
+        SPM_SET_ERR(ctx, "spm_hip_text_pack: the text holds symbols that are not dna4 ranks (>= 4)");
+        return SPM_E_INVALID;
+    }
+    text->d_packed = d;
+    text->packed_words = padded;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_text_is_packed(const spm_text *text) { return text && text->d_packed ? 1 : 0; }
+
 extern "C" int spm_hip_text_download(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t n, uint8_t *dst)
 {
     if (!ctx || !text || begin + n > text->n || (n && !dst)) {
@@ -767,6 +810,7 @@ extern "C" void spm_hip_text_destroy(spm_text *t)
         return;
     if (t->owned)
         hipFree(t->d);
+    hipFree(t->d_packed);
     delete t;
 }
 
@@ -1081,6 +1125,37 @@ int run_filter(const scan_args &A)
         else                                                                                                           \
             LAUNCH_FILTER2(S, (UMAX >= 4 ? 4 : UMAX));                                                                 \
     } while (0)
+    const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
+                            !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
+    if (use_packed) {
+        // p-chunks of 4096 symbols: recompute the span geometry in those units
+        filter_params Q = P;
+        const uint64_t n_pchunks = (Q.hi - (Q.lo & ~4095ull) + 4095) / 4096;
+        uint64_t pspan = n_pchunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 32))) + 1;
+        pspan = std::min<uint64_t>(std::max<uint64_t>(pspan, 4), 4096);
+        pspan = (pspan + 3) & ~3ull;
+        Q.span_chunks = (uint32_t)pspan;
+        Q.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (pspan >= 48 ? 1u : 2u);
+        const uint4 *shadow = reinterpret_cast<const uint4 *>(A.text->d_packed);
+#define LAUNCH_PACKED(S, U2)                                                                                           \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_packed_kernel<S, U2, 2>,                                         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_packed_kernel<S, U2, 2>), dim3(grid), dim3(threads), lds, ctx->stream, Q,      \
+                           shadow);                                                                                    \
+    } while (0)
+        switch (F.stride) {
+        case 16: LAUNCH_PACKED(16, 4); break;
+        case 8: LAUNCH_PACKED(8, 4); break;
+        case 4: LAUNCH_PACKED(4, 2); break;
+        case 2: LAUNCH_PACKED(2, 1); break;
+        default:
+            // stride 1 has 16 windows per word: 4 words already fill the 32-bit survivor mask twice over
+            SPM_SET_ERR(ctx, "internal: packed filter with stride 1");
+            return SPM_E_UNSUPPORTED;
+        }
+#undef LAUNCH_PACKED
+    } else
     switch (F.stride) {
     case 16: LAUNCH_FILTER(16, 8); break;
     case 8: LAUNCH_FILTER(8, 8); break;

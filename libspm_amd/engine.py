@@ -95,6 +95,15 @@ class Text:
     def device_ptr(self) -> int:
         return int(capi.lib().spm_hip_text_device_ptr(self._h) or 0)
 
+    def pack(self):
+        """Build the optional 2-bit shadow (dna4 only): later seed-filter scans stream a quarter of the bytes."""
+        _check(capi.lib().spm_hip_text_pack(self.ctx._h, self._h), self.ctx._h)
+        return self
+
+    @property
+    def packed(self) -> bool:
+        return bool(capi.lib().spm_hip_text_is_packed(self._h))
+
     def download(self, begin: int, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.uint8)
         _check(capi.lib().spm_hip_text_download(self.ctx._h, self._h, begin, n,
@@ -192,13 +201,13 @@ class Hits:
 
 def scan(ctx: Context, text: Text, pats: PatternSet, begin: int = 0, end: int | None = None, *,
          engine: int = capi.ENGINE_AUTO, left_context: bool = False, pos_offset: int = 0, max_hits: int = 0,
-         state_in: np.ndarray | None = None, want_state: bool = False):
+         state_in: np.ndarray | None = None, want_state: bool = False, flags: int = 0):
     """One scan of text[begin:end) -- seqan_pattern_base::operator() for a whole needle set.
 
     Returns Hits, or (Hits, state_out) when want_state is set."""
     end = len(text) if end is None else end
     opts = capi.ScanOpts(engine=engine, left_context=1 if left_context else 0, pos_offset=pos_offset,
-                         max_hits=max_hits, reserved0=0, reserved=0)
+                         max_hits=max_hits, flags=flags, reserved=0)
     h = C.c_void_p()
     st_in = state_in.ctypes.data if state_in is not None else None
     st_out = None
@@ -211,10 +220,10 @@ def scan(ctx: Context, text: Text, pats: PatternSet, begin: int = 0, end: int | 
 
 
 def scan_segments(ctx: Context, text: Text, pats: PatternSet, seg_offsets, *, engine: int = capi.ENGINE_AUTO,
-                  max_hits: int = 0) -> Hits:
+                  max_hits: int = 0, flags: int = 0) -> Hits:
     """Scan a batch of independent haystacks stored back to back (segment s = text[off[s]:off[s+1]]) in one launch."""
     offs = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
-    opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, reserved0=0, reserved=0)
+    opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, flags=flags, reserved=0)
     h = C.c_void_p()
     _check(capi.lib().spm_hip_scan_segments(ctx._h, text._h, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                                             len(offs) - 1, pats._h, C.byref(opts), C.byref(h)), ctx._h)

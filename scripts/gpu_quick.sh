@@ -6,12 +6,11 @@ OUT=gpurun_out
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1 || { tail -40 $OUT/pytest_gpu.log; exit 1; }
 tail -2 $OUT/pytest_gpu.log
 for w in c3 c2; do
-timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --brute-sample-mib 0 2>&1 | python -c "
+timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --brute-sample-mib 0 2>&1 | tee $OUT/bench_$w.json | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        r=json.loads(l); print('$w', round(r['value'],1), round(r['ms_per_step'],3), round(r['roofline']['kernel_ms'],3), round(r['roofline']['frac'],4), r['hits'], round(r['verify_ms_per_step'],4), r['all_planted_found'])
+        r=json.loads(l); print('$w', round(r['value'],1), round(r['ms_per_step'],3), round(r['roofline']['kernel_ms'],3), round(r['roofline']['frac'],4), r['hits'], r.get('packed_text_shadow'))
     else: print(l.rstrip())
 "
 done
-SPM_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --warmup 1 --text-gib 2 2>&1 | tail -1 | tee $OUT/bench_2rank_gloo.json | cut -c1-400

@@ -476,3 +476,47 @@ def test_dna5_haystack_through_the_seed_filter(spm, ctx, oracle):
     assert pe.filterable
     assert np.array_equal(spm.scan(ctx, text, pe, engine=spm.ENGINE_FILTER).view(),
                           spm.scan(ctx, text, pe, engine=spm.ENGINE_BRUTE).view())
+
+
+@pytest.mark.parametrize("cfg", [("myers", 100, 3, 256), ("myers", 150, 3, 64), ("shiftor", 32, 0, 200),
+                                 ("myers", 64, 3, 64), ("myers", 40, 1, 32)])
+def test_packed_text_shadow_gives_identical_hits(spm, ctx, oracle, cfg):
+    """spm_hip_text_pack: seed-filter scans over the 2-bit shadow == scans over the 1-byte text (== brute), for every
+    stride the filter picks, whole text, ragged sub-ranges with left context, and segmented haystacks."""
+    algo, L, kmax, n_pat = cfg
+    n = (1 << 22) + 12345
+    text = ctx.generate(0x5EED0001, 0, n)
+    needles = _planted_config(spm, oracle, n, n_pat, L, kmax)
+    a = spm.ALGO_MYERS if algo == "myers" else spm.ALGO_SHIFTOR
+    ps = ctx.patterns(a, needles, k=kmax)
+    assert ps.filterable and not text.packed
+    plain = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER).view()
+    brute = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
+    assert np.array_equal(plain, brute)
+    text.pack()
+    assert text.packed
+    packed = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER).view()
+    assert np.array_equal(packed, plain)
+    again = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.capi.SCAN_IGNORE_PACKED).view()
+    assert np.array_equal(again, plain)
+    for lo, hi in ((0, 5000), (4097, 70001), (n - 9000, n), (123457, 123457 + 4096)):
+        want = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=True).view()
+        got = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=True).view()
+        assert np.array_equal(got, want), (lo, hi)
+        want = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE).view()
+        got = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER).view()
+        assert np.array_equal(got, want), (lo, hi, "own haystack")
+    offs = np.array([0, 10, 5000, 5000, 300000, 300100, n], dtype=np.uint64)
+    assert np.array_equal(spm.scan_segments(ctx, text, ps, offs, engine=spm.ENGINE_FILTER).view(),
+                          spm.scan_segments(ctx, text, ps, offs, engine=spm.ENGINE_BRUTE).view())
+
+
+def test_pack_rejects_non_dna4(spm, ctx, oracle):
+    t5 = ctx.upload(np.array([0, 1, 2, 4, 3] * 100, dtype=np.uint8), sigma=5)
+    with pytest.raises(spm.SpmError):
+        t5.pack()
+    import torch
+    bad = torch.full((4096,), 7, dtype=torch.uint8, device="cuda")
+    tw = ctx.wrap(bad.data_ptr(), 4096, sigma=4, keepalive=bad)
+    with pytest.raises(spm.SpmError):
+        tw.pack()
