@@ -1065,7 +1065,11 @@ int run_filter(const scan_args &A)
     P.ht_mask = F.ht_mask;
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
-    const uint32_t threads = (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", 512)));
+    const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
+                            !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
+    // measured best: 8 waves per CU on the 1-byte text (HBM-bound), 16 on the 2-bit shadow (LDS/VALU-bound)
+    const uint32_t threads =
+        (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
     const size_t lds = (size_t)F.lds_words * 4 + 16; // + the workgroup's span-dequeue slot
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
@@ -1125,13 +1129,11 @@ int run_filter(const scan_args &A)
         else                                                                                                           \
             LAUNCH_FILTER2(S, (UMAX >= 4 ? 4 : UMAX));                                                                 \
     } while (0)
-    const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
-                            !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
     if (use_packed) {
         // p-chunks of 4096 symbols: recompute the span geometry in those units
         filter_params Q = P;
         const uint64_t n_pchunks = (Q.hi - (Q.lo & ~4095ull) + 4095) / 4096;
-        uint64_t pspan = n_pchunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 32))) + 1;
+        uint64_t pspan = n_pchunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 8))) + 1;
         pspan = std::min<uint64_t>(std::max<uint64_t>(pspan, 4), 4096);
         pspan = (pspan + 3) & ~3ull;
         Q.span_chunks = (uint32_t)pspan;
