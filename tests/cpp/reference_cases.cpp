@@ -13,6 +13,7 @@
 #include <vector>
 
 #include <libspm/matcher/concept.hpp>
+#include <libspm/matcher/hip_batch.hpp>
 #include <libspm/matcher/horspool_matcher.hpp>
 #include <libspm/matcher/myers_matcher.hpp>
 #include <libspm/matcher/myers_matcher_restorable.hpp>
@@ -242,6 +243,37 @@ static void pigeonhole_cases()
     }
 }
 
+static void batch_cases()
+{
+    // the batch front-end delivers exactly the callbacks of the per-needle matchers, grouped by needle
+    sequence_t const needle2 = "TGACTAGCAC"_dna4;
+    std::vector<sequence_t> const needles{needle, needle2, "ACGT"_dna4};
+    auto batch = spm::batch_myers_matcher{needles, 1};
+    EXPECT_TRUE(spm::window_matcher<decltype(batch)>);
+    EXPECT_EQ(spm::window_size(batch), std::size_t{11});
+    std::vector<std::vector<std::size_t>> got(3), want(3);
+    std::vector<std::vector<int>> got_e(3), want_e(3);
+    batch(haystack, [&](std::size_t i, auto const & finder) {
+        got[i].push_back(seqan2::endPosition(finder));
+        got_e[i].push_back(finder.errors());
+    });
+    for (std::size_t i = 0; i < 3; ++i) {
+        auto single = spm::myers_matcher{needles[i], 1};
+        single(haystack, [&](auto const & finder) {
+            want[i].push_back(seqan2::endPosition(finder));
+            want_e[i].push_back(finder.errors());
+        });
+        EXPECT_TRUE(got[i] == want[i] && got_e[i] == want_e[i] && !want[i].empty());
+    }
+    EXPECT_TRUE(std::ranges::equal(got[0], std::vector<std::size_t>{13, 14, 15, 24, 25, 26, 35, 36, 37}));
+    auto exact = spm::batch_shiftor_matcher{needles};
+    std::vector<std::vector<std::size_t>> begins(3);
+    exact(haystack, [&](std::size_t i, auto const & finder) { begins[i].push_back(seqan2::beginPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(begins[0], std::vector<std::size_t>{9, 20, 31}));
+    EXPECT_TRUE(std::ranges::equal(begins[1], std::vector<std::size_t>{3, 14, 25}));
+    EXPECT_TRUE(std::ranges::equal(begins[2], std::vector<std::size_t>{0, 11, 22, 33}));
+}
+
 static void alphabet_cases()
 {
     static_assert(sizeof(spm::dna4) == 1 && sizeof(spm::dna5) == 1 && sizeof(spm::dna15) == 1);
@@ -276,6 +308,7 @@ int main()
     restorable_shiftor_cases();
     prefix_cases();
     pigeonhole_cases();
+    batch_cases();
     alphabet_cases();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures;

@@ -520,3 +520,47 @@ def test_pack_rejects_non_dna4(spm, ctx, oracle):
     tw = ctx.wrap(bad.data_ptr(), 4096, sigma=4, keepalive=bad)
     with pytest.raises(spm.SpmError):
         tw.pack()
+
+
+def test_c_abi_error_paths(spm, ctx, oracle):
+    """Bad arguments come back as error codes with a message -- nothing throws across the ABI, nothing is silent."""
+    import ctypes as C
+    L = spm.capi.lib()
+    text = ctx.upload(oracle.encode("ACGTACGT"))
+    ps = ctx.patterns(spm.ALGO_MYERS, [oracle.encode("ACG")], k=1)
+    h = C.c_void_p()
+    assert L.spm_hip_scan(ctx._h, text._h, 5, 3, ps._h, None, None, None, C.byref(h)) == -1          # begin > end
+    assert L.spm_hip_scan(ctx._h, text._h, 0, 99, ps._h, None, None, None, C.byref(h)) == -1         # end > n
+    assert b"invalid" in L.spm_hip_last_error(ctx._h)
+    with pytest.raises(spm.SpmError):                                                                # rank >= sigma
+        ctx.upload(np.array([0, 1, 7], dtype=np.uint8), sigma=4)
+    with pytest.raises(spm.SpmError):                                                                # needle too long
+        ctx.patterns(spm.ALGO_MYERS, [np.zeros(spm.capi.MAX_NEEDLE + 1, np.uint8)], k=0)
+    p5 = ctx.patterns(spm.ALGO_MYERS, [oracle.encode("ACG", 5)], k=0, sigma=5)
+    with pytest.raises(spm.SpmError):                                                                # sigma mismatch
+        spm.scan(ctx, text, p5)
+    short = ctx.patterns(spm.ALGO_MYERS, [oracle.encode("ACGTA")], k=1)                              # q < 16
+    assert not short.filterable
+    with pytest.raises(spm.SpmError):
+        spm.scan(ctx, text, short, engine=spm.ENGINE_FILTER)
+    big = ctx.patterns(spm.ALGO_MYERS, [oracle.encode("A")], k=0)
+    many = ctx.upload(np.zeros(100000, np.uint8))
+    hh = spm.scan(ctx, many, big, max_hits=10)                                                       # hit overflow
+    with pytest.raises(spm.SpmError, match="raise spm_scan_opts.max_hits"):
+        hh.view()
+    with pytest.raises(spm.SpmError):                                                                # unaligned wrap
+        ctx.wrap(text.device_ptr + 1, 4)
+
+
+def test_c1_horspool_plumbing(spm, ctx, oracle):
+    """BASELINE.json configs[0]: Horspool exact, 1 needle |P|=32 over 1 MiB random DNA -- the CPU restatement
+    (Horspool with skip table) against naive search, and the device's exact engine through SPM_ALGO_HORSPOOL."""
+    n = 1 << 20
+    T = oracle.text(0x5EED0001, 0, n)
+    P, at = oracle.pattern(0x5EED0001, 0x5EED0002, n, 0, 32, 0)
+    want = oracle.naive_exact(T, P).tolist()
+    assert at in want
+    assert oracle.horspool(T, P).tolist() == want
+    text = ctx.generate(0x5EED0001, 0, n)
+    got = spm.scan(ctx, text, ctx.patterns(spm.ALGO_HORSPOOL, [P])).view()
+    assert got["pos"].tolist() == want and set(got["score"].tolist()) == {0}
