@@ -107,14 +107,17 @@ struct myers_lane
     uint32_t hp0[PREFIX ? NW : 1];
     int32_t score;
 
-    __device__ __forceinline__ void step(const uint32_t *row /* &peq[c][0][lane] */)
+    __device__ __forceinline__ void step(const uint32_t *row /* &peq[c][0][lane] */) { step_strided(row, 64); }
+
+    // word w of the row sits at row[w * stride] (64 in the brute kernels, blockDim.x in the verify kernel)
+    __device__ __forceinline__ void step_strided(const uint32_t *row, uint32_t stride)
     {
         uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             // 10 VALU per word: v_bitop3_b32 evaluates any 3-input boolean function (truth table with
             // a = 0xF0, b = 0xCC, c = 0xAA), which folds every AND/OR/NOT pair of the recurrence.
-            const uint32_t eq = row[w * 64];
+            const uint32_t eq = row[(size_t)w * stride];
             const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[w], VP[w], 0xA8); // (eq | VN) & VP
             uint32_t cout;
             const uint32_t sum = __builtin_addc(VP[w], t, carry, &cout);

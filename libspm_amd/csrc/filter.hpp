@@ -613,9 +613,9 @@ struct verify_params
     const candidate *cand;
     const unsigned long long *counters; // [1] candidates
     uint64_t cand_cap;
-    const uint64_t *peq64; // [pattern][sigma][NB] unshifted 64-bit Peq words
+    const uint32_t *peq32; // the brute table: [group][sigma+1][nw_table][64], needles top-aligned
     uint32_t sigma;        // alphabet size; LDS holds sigma+1 rows per thread (row sigma = no match)
-    uint32_t pad2;
+    uint32_t nw_table;     // words per needle in that table
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
@@ -630,15 +630,18 @@ struct verify_params
     uint64_t n_segments;
 };
 
-// One lane per candidate.  The lane's Peq rows are staged in LDS ([symbol][word][thread], conflict-free whatever the
-// per-lane symbol) and the text window is read 16 bytes at a time with the next block prefetched, so the per-symbol
-// dependency chain is one LDS read instead of two dependent global loads (0.09 ms -> see profiles for 20 k candidates).
-template <int NB>
+// One lane per candidate.  Same recurrence and layout as the brute kernel (32-bit words, v_bitop3, needles
+// top-aligned so that the score delta is bit 31 of the top word): the candidate's needle rows are staged from the
+// brute table into LDS ([symbol][word][thread], conflict-free whatever the per-lane symbol), only the NWN top words
+// that can hold needle rows are processed, and the text window is read in prefetched 16-byte blocks -- the
+// per-symbol dependency chain is one LDS round trip.
+template <int NWN>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
-    extern __shared__ uint64_t vlds[]; // [sigma + 1][NB][blockDim.x]
+    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x]
     const uint32_t tid = threadIdx.x;
     const uint32_t nthr = blockDim.x;
+    const uint32_t rows = P.sigma + 1;
     unsigned long long n_cand = P.counters[1];
     if (n_cand > P.cand_cap)
         n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
@@ -682,23 +685,23 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         int64_t ws = e_lo - (m + k);
         if (ws < hay_b)
             ws = hay_b;
-        // stage this needle's Peq rows
-        const uint64_t *peq = P.peq64 + (size_t)pat * P.sigma * NB;
-        for (uint32_t i = 0; i < P.sigma * NB; ++i)
-            vlds[(size_t)i * nthr + tid] = peq[i];
+        // stage this needle's rows: brute table [group][row][word][lane], top NWN words
+        const uint32_t *src = P.peq32 + (((size_t)(pat >> 6) * rows) * P.nw_table + (P.nw_table - NWN)) * 64 + (pat & 63);
+        for (uint32_t r = 0; r < rows; ++r)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            vlds[((size_t)P.sigma * NB + b) * nthr + tid] = 0; // symbols outside the alphabet match nothing
-        uint64_t VP[NB], VN[NB];
+            for (int w = 0; w < NWN; ++w)
+                vlds[((size_t)r * NWN + w) * nthr + tid] = src[((size_t)r * P.nw_table + w) * 64];
+        myers_lane<NWN, false> L;
+        {
+            const int32_t off = NWN * 32 - (int32_t)m;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int64_t rows = m - 64 * b;
-            VP[b] = rows >= 64 ? ~0ull : (rows <= 0 ? 0ull : ((1ull << rows) - 1));
-            VN[b] = 0;
+            for (int w = 0; w < NWN; ++w) {
+                const int32_t lo = off - w * 32;
+                L.VP[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+                L.VN[w] = 0;
+            }
+            L.score = (int32_t)m;
         }
-        int32_t score = (int32_t)m;
-        const int lastb = (int)((m - 1) >> 6);
-        const int lastbit = (int)((m - 1) & 63);
         const int64_t blk0 = ws & ~15ll;
         uint4 nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
         for (int64_t blk = blk0; blk < e_hi; blk += 16) {
@@ -713,36 +716,9 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                     continue;
                 uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 0xFF;
                 sym = sym < P.sigma ? sym : P.sigma;
-                const uint64_t *row = vlds + ((size_t)sym * NB) * nthr + tid;
-                uint64_t carry = 0, hp_c = 0, hn_c = 0;
-                uint64_t HPl = 0, HNl = 0;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const uint64_t eq = row[(size_t)b * nthr];
-                    const uint64_t X = eq | VN[b];
-                    const uint64_t t1 = X & VP[b];
-                    const uint64_t s1 = VP[b] + t1;
-                    const uint64_t c1 = s1 < VP[b];
-                    const uint64_t s2 = s1 + carry;
-                    const uint64_t c2 = s2 < s1;
-                    carry = c1 | c2;
-                    const uint64_t D0 = (s2 ^ VP[b]) | X;
-                    const uint64_t HN = VP[b] & D0;
-                    const uint64_t HP = VN[b] | ~(VP[b] | D0);
-                    const uint64_t Xs = (HP << 1) | hp_c;
-                    const uint64_t Ts = (HN << 1) | hn_c;
-                    hp_c = HP >> 63;
-                    hn_c = HN >> 63;
-                    VN[b] = Xs & D0;
-                    VP[b] = Ts | ~(Xs | D0);
-                    if (b == lastb) {
-                        HPl = HP;
-                        HNl = HN;
-                    }
-                }
-                score += (int32_t)((HPl >> lastbit) & 1) - (int32_t)((HNl >> lastbit) & 1);
+                L.step_strided(vlds + ((size_t)sym * NWN) * nthr + tid, nthr);
                 const int64_t e = p + 1;
-                if (score <= (int32_t)k && e >= e_lo) {
+                if (L.score <= (int32_t)k && e >= e_lo) {
                     // dedupe across the seeds of one occurrence
                     const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
                     uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
@@ -760,10 +736,9 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                             atomicAdd(P.overflow, 1ull);
                     }
                     if (fresh) {
-                        // the lanes that reach this point together share one atomic (ballot/popc); a per-hit
-                        // atomicAdd on the single counter costs ~11 ns each -- 4.6 ms for C4's 400 k hits
+                        // the lanes that reach this point together share one atomic (ballot/popc)
                         wave_append_hits(true, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
-                                         score, P.hits, P.hit_counter, P.hit_cap);
+                                         L.score, P.hits, P.hit_counter, P.hit_cap);
                     }
                 }
             }

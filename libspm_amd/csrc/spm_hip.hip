@@ -54,15 +54,15 @@ struct spm_patterns
     uint32_t max_window = 0;
     uint32_t max_k = 0;
     uint32_t NW = 1;   // 32-bit words per needle in the brute kernels (power of two)
-    uint32_t NB64 = 1; // 64-bit words per needle in the verify kernel (power of two)
     bool is_myers() const { return algo == SPM_ALGO_MYERS || algo == SPM_ALGO_MYERS_PREFIX; }
     // device
     uint32_t *d_peq = nullptr; // [group][sigma+1][NW][64], needles top-aligned
     uint32_t *d_peq_bot = nullptr; // Myers only: same shape, needles bottom-aligned (cut-off kernel)
+    uint32_t *d_peq_verify = nullptr; // exact matchers: Myers-style match masks (top-aligned) for the verify kernel;
+                                      // for Myers sets verification reads d_peq itself
     uint32_t *d_hp0 = nullptr; // prefix: [group][NW][64]
     int32_t *d_m = nullptr;
     int32_t *d_k = nullptr;
-    uint64_t *d_peq64 = nullptr; // verify: [pattern][4][NB64]
     std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
     uint32_t filter_stride = 0;
 };
@@ -345,7 +345,6 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         ps->max_window = std::max(ps->max_window, m + kk);
     }
     ps->NW = next_pow2(std::max(1u, (ps->max_m + 31) / 32));
-    ps->NB64 = next_pow2(std::max(1u, (ps->max_m + 63) / 64));
     const uint32_t NW = ps->NW, rows = sigma + 1;
     const bool myers = ps->is_myers();
 
@@ -393,6 +392,26 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         }
     SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq, peq.size() * sizeof(uint32_t)));
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq, peq.data(), peq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!myers && sigma <= 5) {
+        // the filter engine verifies exact matchers with the Myers recurrence at k = 0: match masks, not Shift-Or's
+        std::vector<uint32_t> vq(peq.size(), 0);
+        for (uint32_t p = 0; p < n_patterns; ++p) {
+            const uint32_t m = (uint32_t)ps->m[p];
+            if (m == 0)
+                continue;
+            const uint32_t off = NW * 32 - m, g = p / 64, l = p % 64;
+            for (uint32_t row = 0; row < rows; ++row)
+                for (uint32_t b = 0; b < off; ++b)
+                    vq[(((size_t)g * rows + row) * NW + b / 32) * 64 + l] |= 1u << (b % 32);
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint8_t c = ps->ranks[ps->offsets[p] + j];
+                if (c < sigma)
+                    vq[(((size_t)g * rows + c) * NW + (off + j) / 32) * 64 + l] |= 1u << ((off + j) % 32);
+            }
+        }
+        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq_verify, vq.size() * sizeof(uint32_t)));
+        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq_verify, vq.data(), vq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (algo == SPM_ALGO_MYERS) {
         std::vector<uint32_t> bot(peq.size(), 0);
         for (uint32_t p = 0; p < n_patterns; ++p)
@@ -413,18 +432,8 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_m, ps->m.data(), ps->m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 
-    // ---- filter engine tables ----
+    // ---- filter engine tables (verification reads the brute table) ----
     if ((sigma == 4 || sigma == 5) && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
-        const uint32_t NB = ps->NB64;
-        std::vector<uint64_t> p64((size_t)n_patterns * sigma * NB, 0);
-        for (uint32_t p = 0; p < n_patterns; ++p)
-            for (uint32_t j = 0; j < (uint32_t)ps->m[p]; ++j) {
-                const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                if (c < sigma)
-                    p64[((size_t)p * sigma + c) * NB + j / 64] |= 1ull << (j % 64);
-            }
-        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq64, p64.size() * sizeof(uint64_t)));
-        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq64, p64.data(), p64.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         int rc = build_filter_index(ctx, ps.get());
         if (rc != SPM_OK)
             return rc;
@@ -439,10 +448,10 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
         return;
     hipFree(p->d_peq);
     hipFree(p->d_peq_bot);
+    hipFree(p->d_peq_verify);
     hipFree(p->d_hp0);
     hipFree(p->d_m);
     hipFree(p->d_k);
-    hipFree(p->d_peq64);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
@@ -871,25 +880,33 @@ void launch_brute(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3
     }
 }
 
-template <int NB>
-void launch_verify_nb(const verify_params &V, dim3 grid, hipStream_t s)
+template <int NWN>
+void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
-    // LDS holds 4*NB uint64 per thread; keep the block within 128 KiB
-    const uint32_t threads = NB <= 8 ? 256u : (NB <= 16 ? 128u : 64u);
-    const size_t lds = (size_t)(V.sigma + 1) * NB * 8 * threads;
-    hipFuncSetAttribute((const void *)verify_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((verify_kernel<NB>), grid, dim3(threads), lds, s, V);
+    // LDS holds (sigma+1)*NWN words per thread; keep the block within ~128 KiB
+    uint32_t threads = 256;
+    while (threads > 64 && (size_t)(V.sigma + 1) * NWN * 4 * threads > 128 * 1024)
+        threads >>= 1;
+    const size_t lds = (size_t)(V.sigma + 1) * NWN * 4 * threads;
+    hipFuncSetAttribute((const void *)verify_kernel<NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((verify_kernel<NWN>), grid, dim3(threads), lds, s, V);
 }
 
-void launch_verify(uint32_t NB, const verify_params &V, dim3 grid, hipStream_t s)
+// nwn = 32-bit words that can hold needle rows = ceil(max |P| / 32), rounded up to an instantiated width
+void launch_verify(uint32_t nwn, const verify_params &V, dim3 grid, hipStream_t s)
 {
-    switch (NB) {
-    case 1: launch_verify_nb<1>(V, grid, s); break;
-    case 2: launch_verify_nb<2>(V, grid, s); break;
-    case 4: launch_verify_nb<4>(V, grid, s); break;
-    case 8: launch_verify_nb<8>(V, grid, s); break;
-    case 16: launch_verify_nb<16>(V, grid, s); break;
-    default: launch_verify_nb<32>(V, grid, s); break;
+    switch (nwn) {
+    case 1: launch_verify_nw<1>(V, grid, s); break;
+    case 2: launch_verify_nw<2>(V, grid, s); break;
+    case 3: launch_verify_nw<3>(V, grid, s); break;
+    case 4: launch_verify_nw<4>(V, grid, s); break;
+    case 5: launch_verify_nw<5>(V, grid, s); break;
+    case 6: launch_verify_nw<6>(V, grid, s); break;
+    case 7: launch_verify_nw<7>(V, grid, s); break;
+    case 8: launch_verify_nw<8>(V, grid, s); break;
+    case 16: launch_verify_nw<16>(V, grid, s); break;
+    case 32: launch_verify_nw<32>(V, grid, s); break;
+    default: launch_verify_nw<64>(V, grid, s); break;
     }
 }
 
@@ -1183,8 +1200,9 @@ int run_filter(const scan_args &A)
     V.cand = d_cand;
     V.counters = H->d_count;
     V.cand_cap = cand_cap;
-    V.peq64 = ps->d_peq64;
+    V.peq32 = ps->d_peq_verify ? ps->d_peq_verify : ps->d_peq;
     V.sigma = ps->sigma;
+    V.nw_table = ps->NW;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;
@@ -1204,7 +1222,10 @@ int run_filter(const scan_args &A)
         V.seg_offsets = d_seg;
         V.n_segments = A.n_segments;
     }
-    launch_verify(ps->NB64, V, dim3(ctx->n_cu * 4), ctx->stream);
+    uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
+    if (nwn > 8)
+        nwn = ps->NW; // power of two beyond 8 words
+    launch_verify(nwn, V, dim3(ctx->n_cu * 4), ctx->stream);
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
     H->cand_cap = cand_cap;
