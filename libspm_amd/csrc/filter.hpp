@@ -616,6 +616,8 @@ struct verify_params
     const uint32_t *peq32; // the brute table: [group][sigma+1][nw_table][64], needles top-aligned
     uint32_t sigma;        // alphabet size; LDS holds sigma+1 rows per thread (row sigma = no match)
     uint32_t nw_table;     // words per needle in that table
+    uint32_t max_k;        // largest k of the set: 2*max_k + 1 end-position slots per candidate
+    uint32_t pad3;
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
@@ -638,10 +640,13 @@ struct verify_params
 template <int NWN>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
-    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x]
+    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x] words, then [2*max_k + 1][blockDim.x] uint16
     const uint32_t tid = threadIdx.x;
     const uint32_t nthr = blockDim.x;
     const uint32_t rows = P.sigma + 1;
+    uint16_t *hitbuf = reinterpret_cast<uint16_t *>(vlds + (size_t)rows * NWN * nthr);
+    for (uint32_t r = 0; r <= 2 * P.max_k; ++r)
+        hitbuf[(size_t)r * nthr + tid] = 0;
     unsigned long long n_cand = P.counters[1];
     if (n_cand > P.cand_cap)
         n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
@@ -691,6 +696,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 #pragma unroll
             for (int w = 0; w < NWN; ++w)
                 vlds[((size_t)r * NWN + w) * nthr + tid] = src[((size_t)r * P.nw_table + w) * 64];
+        bool any_hit = false;
         myers_lane<NWN, false> L;
         {
             const int32_t off = NWN * 32 - (int32_t)m;
@@ -719,10 +725,28 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                 L.step_strided(vlds + ((size_t)sym * NWN) * nthr + tid, nthr);
                 const int64_t e = p + 1;
                 if (L.score <= (int32_t)k && e >= e_lo) {
+                    // remember the hit; emission is deferred until the whole wave has finished scanning so that the
+                    // CAS / append atomics (1-2 us each) are issued once per end-position slot for all lanes together
+                    // instead of stalling the wave at ~every lane's own hit
+                    hitbuf[(size_t)(e - e_lo) * nthr + tid] = (uint16_t)(L.score + 1);
+                    any_hit = true;
+                }
+            }
+        }
+        // ---- deferred emission: slot r = end position e_lo + r ----
+        if (__ballot(any_hit) != 0) {
+            for (int64_t r = 0; r <= 2 * (int64_t)P.max_k; ++r) {
+                uint32_t sc1 = 0;
+                if (any_hit && r <= e_hi - e_lo) {
+                    sc1 = hitbuf[(size_t)r * nthr + tid];
+                    hitbuf[(size_t)r * nthr + tid] = 0;
+                }
+                bool fresh = false;
+                const int64_t e = e_lo + r;
+                if (sc1) {
                     // dedupe across the seeds of one occurrence
                     const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
                     uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-                    bool fresh = false;
                     for (uint32_t tries = 0; tries <= P.seen_mask; ++tries) {
                         const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
                         if (old == ~0ull) {
@@ -735,12 +759,10 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                         if (tries == P.seen_mask)
                             atomicAdd(P.overflow, 1ull);
                     }
-                    if (fresh) {
-                        // the lanes that reach this point together share one atomic (ballot/popc)
-                        wave_append_hits(true, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
-                                         L.score, P.hits, P.hit_counter, P.hit_cap);
-                    }
                 }
+                if (__ballot(fresh) != 0)
+                    wave_append_hits(fresh, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
+                                     (int32_t)sc1 - 1, P.hits, P.hit_counter, P.hit_cap);
             }
         }
     }

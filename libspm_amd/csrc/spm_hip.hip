@@ -885,9 +885,10 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
     // LDS holds (sigma+1)*NWN words per thread; keep the block within ~128 KiB
     uint32_t threads = 256;
-    while (threads > 64 && (size_t)(V.sigma + 1) * NWN * 4 * threads > 128 * 1024)
+    const size_t per_thread = (size_t)(V.sigma + 1) * NWN * 4 + 2 * (2 * (size_t)V.max_k + 1);
+    while (threads > 64 && per_thread * threads > 128 * 1024)
         threads >>= 1;
-    const size_t lds = (size_t)(V.sigma + 1) * NWN * 4 * threads;
+    const size_t lds = per_thread * threads;
     hipFuncSetAttribute((const void *)verify_kernel<NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_kernel<NWN>), grid, dim3(threads), lds, s, V);
 }
@@ -1203,6 +1204,7 @@ int run_filter(const scan_args &A)
     V.peq32 = ps->d_peq_verify ? ps->d_peq_verify : ps->d_peq;
     V.sigma = ps->sigma;
     V.nw_table = ps->NW;
+    V.max_k = ps->max_k;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;
