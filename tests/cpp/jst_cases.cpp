@@ -69,8 +69,9 @@ static needle_set make_needles(spm::journaled_sequence_tree const & jst, int alg
         std::vector<std::uint8_t> hap = jst.haplotype(h).materialize();
         std::size_t const at = (r >> 20) % (hap.size() - L - 4);
         std::vector<std::uint8_t> nd(hap.begin() + at, hap.begin() + at + L);
-        for (unsigned e = 0; e < (i % (k + 1)); ++e) // plant up to k substitutions
-            nd[(r >> (8 + 7 * e)) % L] ^= 1;
+        unsigned const n_edits = k > 8 ? static_cast<unsigned>((i * 9) % (k + 1)) : static_cast<unsigned>(i % (k + 1));
+        for (unsigned e = 0; e < n_edits; ++e) // plant up to k substitutions
+            nd[spm_oracle_mix64(r + 77 * e) % L] ^= 1;
         cat.insert(cat.end(), nd.begin(), nd.end());
         off.push_back(static_cast<std::uint32_t>(cat.size()));
         ks.push_back(static_cast<std::uint16_t>(k));
@@ -231,6 +232,17 @@ static void synthetic_case()
     EXPECT_TRUE(got == want);
     EXPECT_TRUE(got.size() >= 64);
     EXPECT_TRUE(st.context_symbols * 4 < st.haplotype_symbols);
+
+    // C5-shaped needles: |P| = 1024, k <= 64 (q = 15 < 16: no seed filter, the cut-off brute kernel scans the
+    // contexts as segmented haystacks).  Needles carry up to 64 planted substitutions.
+    needle_set big = make_needles(jst, SPM_ALGO_MYERS, 1024, 64, 8);
+    auto got_big = jst.search(big.compiled.get(), big.window, big.lens, false, 0, &st);
+    auto want_big = linear_scans(jst, big);
+    std::printf("synthetic, 8 needles |P|=1024 k=64: %zu hits; device scanned %llu symbols for %llu (%.1fx less)\n",
+                got_big.size(), (unsigned long long)st.context_symbols, (unsigned long long)st.haplotype_symbols,
+                double(st.haplotype_symbols) / double(st.context_symbols));
+    EXPECT_TRUE(got_big == want_big);
+    EXPECT_TRUE(got_big.size() >= 8);
 }
 
 int main(int argc, char ** argv)
