@@ -58,6 +58,13 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+// a value that is the same in every lane, moved to SGPRs (the compiler cannot prove uniformity of a loaded value)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
 // append the hits of one wave: ballot + popc prefix, one atomic per wave
 __device__ __forceinline__ void wave_append_hits(bool is_hit, uint64_t pos, uint32_t pattern, int32_t score,
                                                  spm_hit *hits, unsigned long long *counter, uint64_t cap)
@@ -181,9 +188,9 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
             own_hi = P.scan_end;
         uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
         if (P.tile_tab) { // segmented haystacks: geometry comes from the host's tile table
-            scan_lo = P.tile_tab[3 * (uint64_t)tile];
-            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
-            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+            scan_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile]);
+            own_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 1]);
+            own_hi = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 2]);
         }
         const bool resume = P.has_state && tile == 0;
         if (resume)
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
                     }
                 }
             } else if (full && cbase >= own_lo) {
-                // owned interior chunk: recurrence + hit test, no range checks
+                // owned interior chunk: recurrence + hit test, no range checks (batching the test over 4 symbols, as the
+                // Shift-Or kernel does, measured 4 % slower here: the four kept scores cost more than three ballots)
                 for (uint32_t j = 0; j < 64; ++j) {
                     const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
 #pragma unroll
@@ -332,9 +340,9 @@ __global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
             own_hi = P.scan_end;
         uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
         if (P.tile_tab) {
-            scan_lo = P.tile_tab[3 * (uint64_t)tile];
-            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
-            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+            scan_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile]);
+            own_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 1]);
+            own_hi = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 2]);
         }
 
         // ---- cold start: D[i][0] = i, band = rows with D <= k ----
@@ -400,28 +408,27 @@ __global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
 
         auto step = [&](uint32_t c, bool report, uint64_t pos) {
             const uint32_t *row = lane_peq + (size_t)c * NW * 64;
+            // word 0 is inside every lane's band (a >= 1)
             uint32_t hpl, hnl;
-            if (amax == 1) {
-                // every lane of the wave has a one-word band
+            uint32_t carry;
+            {
                 const uint32_t eq = row[0];
                 const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[0], VP[0], 0xA8);
-                const uint32_t sum = VP[0] + t;
+                const uint32_t sum = __builtin_addc(VP[0], t, 0u, &carry);
                 const uint32_t X = eq | VN[0];
                 const uint32_t D0 = __builtin_amdgcn_bitop3_b32(sum, VP[0], X, 0xBE);
-                const uint32_t HN = VP[0] & D0;
-                const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN[0], VP[0], D0, 0xF1);
-                const uint32_t Xs = HP << 1;
-                const uint32_t Ts = HN << 1;
+                hnl = VP[0] & D0;
+                hpl = __builtin_amdgcn_bitop3_b32(VN[0], VP[0], D0, 0xF1);
+                const uint32_t Xs = hpl << 1;
+                const uint32_t Ts = hnl << 1;
                 VN[0] = Xs & D0;
                 VP[0] = __builtin_amdgcn_bitop3_b32(Ts, Xs, D0, 0xF1);
-                hpl = HP;
-                hnl = HN;
-            } else {
-                uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
-                hpl = 0;
-                hnl = 0;
+            }
+            if (amax > 1) {
+                // some lane has a wider band: the remaining words, masked per lane
+                uint32_t hp_prev = hpl, hn_prev = hnl;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
+                for (int w = 1; w < NW; ++w) {
                     if (w < amax) {
                         const uint32_t eq = row[w * 64];
                         const uint32_t t = __builtin_amdgcn_bitop3_b32(eq, VN[w], VP[w], 0xA8);
@@ -433,8 +440,7 @@ __global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
                         const uint32_t HP = __builtin_amdgcn_bitop3_b32(VN[w], VP[w], D0, 0xF1);
                         const uint32_t Xs = alignbit(HP, hp_prev, 31);
                         const uint32_t Ts = alignbit(HN, hn_prev, 31);
-                        const bool in_band = w < a; // lanes whose band ends earlier keep their (inactive) words
-                        if (in_band) {
+                        if (w < a) { // lanes whose band ends earlier keep their (inactive) words
                             VN[w] = Xs & D0;
                             VP[w] = __builtin_amdgcn_bitop3_b32(Ts, Xs, D0, 0xF1);
                             carry = cout;
@@ -532,9 +538,9 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
             own_hi = P.scan_end;
         uint64_t scan_lo = own_lo >= P.ctx_begin + P.warm ? own_lo - P.warm : P.ctx_begin;
         if (P.tile_tab) { // segmented haystacks: geometry comes from the host's tile table
-            scan_lo = P.tile_tab[3 * (uint64_t)tile];
-            own_lo = P.tile_tab[3 * (uint64_t)tile + 1];
-            own_hi = P.tile_tab[3 * (uint64_t)tile + 2];
+            scan_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile]);
+            own_lo = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 1]);
+            own_hi = uniform_u64(P.tile_tab[3 * (uint64_t)tile + 2]);
         }
         const bool resume = P.has_state && tile == 0;
         if (resume)
@@ -587,16 +593,26 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
                     }
                 }
             } else if (full && cbase >= own_lo) {
+                // owned interior chunk.  Hits are tested once per 4 symbols: an occurrence ends at one of them iff
+                // bit 31 is clear in the AND of the four top words; only then are the four looked at one by one.
                 for (uint32_t j = 0; j < 64; ++j) {
                     const uint32_t w4 = __builtin_amdgcn_readlane(v, j);
+                    uint32_t top[4];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         uint32_t c = (w4 >> (8 * s)) & 0xFF;
                         step(c < sigma ? c : sigma);
-                        const bool hit = active_lane && ((int32_t)R[NW - 1] >= 0); // bit 31 clear
-                        if (__ballot(hit) != 0)
-                            wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 - (uint64_t)my_m + P.pos_offset,
-                                             group * 64 + lane, 0, P.hits, P.counters, P.hit_cap);
+                        top[s] = R[NW - 1];
+                    }
+                    const bool any = active_lane && ((int32_t)(top[0] & top[1] & top[2] & top[3]) >= 0);
+                    if (__ballot(any) != 0) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const bool hit = active_lane && ((int32_t)top[s] >= 0); // bit 31 clear
+                            if (__ballot(hit) != 0)
+                                wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 - (uint64_t)my_m + P.pos_offset,
+                                                 group * 64 + lane, 0, P.hits, P.counters, P.hit_cap);
+                        }
                     }
                 }
             } else {
