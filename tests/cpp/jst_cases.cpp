@@ -130,6 +130,33 @@ static void fixture_cases(char const * vcf, char const * haplotypes)
     }
     std::printf("%s: %zu/100 haplotypes reproduce the fixture FASTA\n", vcf, equal);
     EXPECT_TRUE(equal == 100);
+    // the context builder works from the allele lists alone (no haplotype is materialised): for every haplotype the
+    // owned parts of its contexts, in order, must spell the haplotype, and every context must carry window-1 symbols
+    // of left context (or start at the haplotype's first symbol)
+    for (std::size_t window : {33u, 103u}) {
+        auto X = jst.build_contexts(window, 4 * window);
+        std::vector<std::vector<std::pair<std::uint64_t, std::size_t>>> per_h(100);
+        for (std::size_t c = 0; c < X.contexts.size(); ++c)
+            for (auto const & m : X.contexts[c].members)
+                per_h[m.haplotype].emplace_back(m.ctx_lo, c);
+        std::size_t good = 0;
+        for (std::size_t h = 0; h < 100; ++h) {
+            std::sort(per_h[h].begin(), per_h[h].end());
+            std::vector<std::uint8_t> spelled;
+            bool ok = true;
+            for (auto const & [lo, c] : per_h[h]) {
+                auto const & cx = X.contexts[c];
+                ok = ok && (lo + cx.owned_from == spelled.size()) && (cx.owned_from == window - 1 || lo == 0);
+                // the left context must equal what was spelled before
+                for (std::size_t i = 0; i < cx.owned_from && ok; ++i)
+                    ok = X.buffer[cx.offset + i] == spelled[lo + i];
+                spelled.insert(spelled.end(), X.buffer.begin() + cx.offset + cx.owned_from,
+                               X.buffer.begin() + cx.offset + cx.length);
+            }
+            good += ok && spelled == expected[h].ranks;
+        }
+        EXPECT_TRUE(good == 100);
+    }
     if (cpu_only)
         return; // --cpu: journal + ingestion checks only (no device)
 
