@@ -174,6 +174,14 @@ uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n
                                uint32_t kmax, uint8_t *out);
 uint64_t spm_hip_mix64(uint64_t z);
 
+/* Host-only self-check of the seed index (no device, no context): builds the level-1 / level-2 tables exactly as
+ * spm_hip_patterns_create does and verifies what the filter's losslessness rests on -- every indexed 16-symbol window of
+ * every seed is found at both levels, every needle sits in exactly one pass, the stride fits every seed.
+ * stats[8] = {passes, stride, keys, windows checked, windows missing, level-1 false positives, trials, hash variant}.
+ * Returns SPM_OK iff nothing is missing. */
+int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, const uint32_t *offsets, uint32_t n_patterns,
+                          const uint16_t *k, uint32_t sigma, uint64_t *stats);
+
 const char *spm_hip_version(void);
 
 #ifdef __cplusplus

@@ -106,6 +106,7 @@ def lib():
         "spm_hip_synth_pattern": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.c_uint32, u8p]),
         "spm_hip_mix64": (C.c_uint64, [C.c_uint64]),
+        "spm_hip_host_selftest": (C.c_int, [C.c_int, u8p, u32p, C.c_uint32, u16p, C.c_uint32, C.POINTER(C.c_uint64)]),
         "spm_hip_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
@@ -124,5 +125,5 @@ EXPORTS = [
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
     "spm_hip_hits_copy_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
-    "spm_hip_mix64", "spm_hip_version",
+    "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
 ]

@@ -38,7 +38,12 @@ struct filter_index
     uint64_t n_keys = 0;
     uint32_t *d_bitmap = nullptr;
     uint2 *d_ht = nullptr;
+    // host copies, kept only by spm_hip_host_selftest (no device involved)
+    std::vector<uint32_t> h_image;
+    std::vector<uint2> h_ht;
 };
+
+static thread_local bool g_index_host_only = false;
 
 struct spm_patterns
 {
@@ -299,6 +304,12 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
         while (ht[slot].y != kHtEmpty)
             slot = (slot + 1) & F.ht_mask;
         ht[slot] = make_uint2(e.key, e.val);
+    }
+    if (g_index_host_only) {
+        F.h_image = bitmap;
+        F.h_ht = ht;
+        F.ok = true;
+        return SPM_OK;
     }
     SPM_HIP_CHECK(ctx, hipMalloc(&F.d_bitmap, words * sizeof(uint32_t)));
     SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint2)));
@@ -1553,5 +1564,119 @@ extern "C" uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat,
 }
 
 extern "C" uint64_t spm_hip_mix64(uint64_t z) { return mix64(z); }
+
+// Host-only self-check of the seed index (no device, no context): builds the tables exactly as
+// spm_hip_patterns_create does and verifies the properties the filter's losslessness rests on.
+extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, const uint32_t *offsets, uint32_t n_patterns,
+                                     const uint16_t *k, uint32_t sigma, uint64_t *stats)
+{
+    if (!ranks_concat || !offsets || !stats || n_patterns == 0)
+        return SPM_E_INVALID;
+    spm_patterns ps;
+    ps.algo = algo;
+    ps.n = n_patterns;
+    ps.sigma = sigma;
+    ps.offsets.assign(offsets, offsets + n_patterns + 1);
+    ps.ranks.assign(ranks_concat, ranks_concat + offsets[n_patterns]);
+    ps.m.assign(n_patterns, 0);
+    ps.k.assign(n_patterns, 0);
+    for (uint32_t p = 0; p < n_patterns; ++p) {
+        ps.m[p] = (int32_t)(offsets[p + 1] - offsets[p]);
+        ps.k[p] = (ps.is_myers() && k) ? k[p] : 0;
+    }
+    g_index_host_only = true;
+    const int rc = build_filter_index(nullptr, &ps);
+    g_index_host_only = false;
+    memset(stats, 0, 8 * sizeof(uint64_t));
+    if (rc != SPM_OK)
+        return rc;
+    stats[0] = ps.fidx.size();   // passes (0 = the seed filter does not apply)
+    stats[1] = ps.filter_stride; // S
+    if (ps.fidx.empty())
+        return SPM_OK;
+    const uint32_t S = ps.filter_stride;
+    // level-1 membership test, exactly as the kernels evaluate it
+    auto level1 = [&](const filter_index &F, uint32_t key) -> bool {
+        if (F.hash_variant == 2) {
+            const uint16_t *fp = reinterpret_cast<const uint16_t *>(F.h_image.data());
+            const uint16_t *disp = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(F.h_image.data()) + F.chd_disp_off);
+            const chd_hashes hh = chd_hash(key);
+            const uint32_t d = disp[hh.x >> F.chd_bucket_shift];
+            return fp[chd_slot(hh, d, F.chd_slot_mask)] == hh.f;
+        }
+        const uint32_t idx_mask = F.bitmap_words * 32 - 1;
+        for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
+            const uint32_t x = (F.hash_variant ? bloom_hash<1>(key, pr) : bloom_hash<0>(key, pr)) & idx_mask;
+            if (!((F.h_image[x >> 5] >> (x & 31)) & 1))
+                return false;
+        }
+        return true;
+    };
+    auto level2 = [&](const filter_index &F, uint32_t key, uint32_t val) -> bool {
+        uint32_t slot = ht_hash(key) & F.ht_mask;
+        for (;;) {
+            const uint2 e = F.h_ht[slot];
+            if (e.y == kHtEmpty)
+                return false;
+            if (e.x == key && e.y == val)
+                return true;
+            slot = (slot + 1) & F.ht_mask;
+        }
+    };
+    // every needle belongs to exactly one pass; every indexed window of every seed is found at both levels
+    uint64_t checked = 0, missing = 0;
+    {
+        uint64_t keys_total = 0;
+        for (const filter_index &F : ps.fidx)
+            keys_total += F.n_keys;
+        stats[2] = keys_total;
+        uint64_t expect = 0;
+        for (uint32_t p = 0; p < n_patterns; ++p)
+            expect += (uint64_t)(ps.k[p] + 1) * S;
+        if (expect != keys_total)
+            return SPM_E_INVALID;
+    }
+    size_t fi = 0;
+    uint64_t in_pass = 0;
+    for (uint32_t p = 0; p < n_patterns; ++p) {
+        const uint32_t m = (uint32_t)ps.m[p], kk = (uint32_t)ps.k[p], q = m / (kk + 1);
+        if (S > q - (kKeyH - 1))
+            return SPM_E_INVALID; // sampling would miss occurrences
+        const uint64_t mine = (uint64_t)(kk + 1) * S;
+        while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
+            if (in_pass != ps.fidx[fi].n_keys)
+                return SPM_E_INVALID;
+            ++fi;
+            in_pass = 0;
+        }
+        if (fi >= ps.fidx.size())
+            return SPM_E_INVALID;
+        in_pass += mine;
+        const filter_index &F = ps.fidx[fi];
+        const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
+        for (uint32_t j = 0; j <= kk; ++j)
+            for (uint32_t r = 0; r < S; ++r) {
+                uint32_t key = 0;
+                for (uint32_t i = 0; i < kKeyH; ++i) {
+                    const uint8_t c = pat[j * q + r + i];
+                    key |= (uint32_t)((sigma == 5 && c == 4) ? 3u : (c & 3u)) << (2 * i);
+                }
+                ++checked;
+                if (!level1(F, key) || !level2(F, key, (p << 11) | (j * q + r)))
+                    ++missing;
+            }
+    }
+    stats[3] = checked;
+    stats[4] = missing;
+    // false-positive rate of level 1 on pseudo-random keys (first pass)
+    uint64_t fp = 0;
+    const uint64_t trials = 1 << 20;
+    for (uint64_t t = 0; t < trials; ++t)
+        fp += level1(ps.fidx[0], (uint32_t)mix64(0xC0FFEE + t)) ? 1 : 0;
+    stats[5] = fp;
+    stats[6] = trials;
+    stats[7] = ps.fidx[0].hash_variant;
+    return missing ? SPM_E_INVALID : SPM_OK;
+}
 
 extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.1 (gfx950)"; }

@@ -1,0 +1,65 @@
+"""CPU: the host logic of the seed filter -- pigeonhole seeds, stride choice, sub-batching, the perfect-hash
+fingerprint table, the Bloom fallback and the exact key table -- checked without a device through
+spm_hip_host_selftest (the same code spm_hip_patterns_create runs)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def _selftest(spm, algo, needles, k, sigma=4):
+    offs = np.zeros(len(needles) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(x) for x in needles])
+    cat = np.ascontiguousarray(np.concatenate(needles), dtype=np.uint8)
+    ks = np.full(len(needles), k, dtype=np.uint16) if np.isscalar(k) else np.asarray(k, dtype=np.uint16)
+    stats = (C.c_uint64 * 8)()
+    rc = spm.capi.lib().spm_hip_host_selftest(algo, cat.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              offs.ctypes.data_as(C.POINTER(C.c_uint32)), len(needles),
+                                              ks.ctypes.data_as(C.POINTER(C.c_uint16)), sigma, stats)
+    names = ["passes", "stride", "keys", "checked", "missing", "fp", "trials", "hash_variant"]
+    return rc, dict(zip(names, [int(x) for x in stats]))
+
+
+def test_c3_shaped_set_single_pass_fingerprint_table(spm):
+    needles = [spm.synth_pattern(0x5EED0001, 0x5EED0002, 1 << 34, p, 100, 3)[0] for p in range(1024)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, needles, 3)
+    assert rc == 0 and st["missing"] == 0
+    assert st["passes"] == 1 and st["stride"] == 8 and st["keys"] == 1024 * 4 * 8 == st["checked"]
+    assert st["hash_variant"] == 2
+    assert st["fp"] / st["trials"] < 1e-4      # ~ load * 2^-16
+
+
+def test_exact_and_long_needles_and_sub_batches(spm):
+    rng = np.random.default_rng(3)
+    rc, st = _selftest(spm, spm.ALGO_SHIFTOR, [rng.integers(0, 4, 32, dtype=np.uint8) for _ in range(1024)], 0)
+    assert rc == 0 and st["stride"] == 16 and st["passes"] == 1 and st["keys"] == 1024 * 16
+    # 6 000 needles of 150, k = 3: 24 000 seeds -> several passes, stride chosen by the cost model
+    big = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(6000)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, big, 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] >= 2 and st["keys"] == 6000 * 4 * st["stride"]
+    # mixed lengths and k: the stride follows the shortest seed
+    mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
+    assert rc == 0 and st["stride"] == 1 and st["passes"] == 1      # 64 / 4 = 16 -> only stride 1 fits
+    # seeds shorter than a key: the filter does not apply
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8)], 3)
+    assert rc == 0 and st["passes"] == 0
+
+
+def test_dna5_and_bloom_fallback(spm):
+    rng = np.random.default_rng(4)
+    needles = [rng.choice(np.array([0, 1, 2, 4], dtype=np.uint8), 100) for _ in range(256)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, needles, 3, sigma=5)
+    assert rc == 0 and st["passes"] == 1 and st["missing"] == 0
+    with_n = [x.copy() for x in needles]
+    with_n[7][50] = 3
+    rc, st = _selftest(spm, spm.ALGO_MYERS, with_n, 3, sigma=5)
+    assert rc == 0 and st["passes"] == 0                             # an N in a needle: brute engine
+    os.environ["SPM_HIP_FILTER_HASH"] = "1"                          # force the Bloom cascade
+    try:
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 100, dtype=np.uint8) for _ in range(1024)], 3)
+    finally:
+        del os.environ["SPM_HIP_FILTER_HASH"]
+    assert rc == 0 and st["hash_variant"] == 1 and st["missing"] == 0
+    assert st["fp"] / st["trials"] < 2e-3                            # 4 probes at 12.5 % occupancy
