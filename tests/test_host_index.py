@@ -34,10 +34,13 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     rng = np.random.default_rng(3)
     rc, st = _selftest(spm, spm.ALGO_SHIFTOR, [rng.integers(0, 4, 32, dtype=np.uint8) for _ in range(1024)], 0)
     assert rc == 0 and st["stride"] == 16 and st["passes"] == 1 and st["keys"] == 1024 * 16
-    # 6 000 needles of 150, k = 3: 24 000 seeds -> several passes, stride chosen by the cost model
+    # 6 000 needles of 150, k = 3: 24 000 seeds -> the cost model trades stride for passes (stride 2, one pass)
     big = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(6000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, big, 3)
-    assert rc == 0 and st["missing"] == 0 and st["passes"] >= 2 and st["keys"] == 6000 * 4 * st["stride"]
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["stride"] == 2 and st["keys"] == 6000 * 4 * 2
+    # 20 000 needles: 80 000 seeds do not fit one table even at stride 1 -> two passes
+    rc, st = _selftest(spm, spm.ALGO_MYERS, big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)], 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 2 and st["stride"] == 1 and st["keys"] == 80000
     # mixed lengths and k: the stride follows the shortest seed
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
