@@ -8,7 +8,6 @@
 #pragma once
 
 #include <libspm/matcher/restorable_base.hpp>
-#include <libspm/matcher/seqan_restorable_pattern.hpp>
 
 namespace spm
 {
