@@ -35,7 +35,8 @@
 namespace spm_hip
 {
 
-constexpr uint32_t kKeyH = 16;          // symbols per key
+constexpr uint32_t kKeyMax = 16; // symbols per key: 16 whenever the seeds allow it, down to kKeyMin for short seeds
+constexpr uint32_t kKeyMin = 12;
 constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
 
 struct candidate
@@ -55,6 +56,8 @@ struct filter_params
     uint32_t n_probes;        // Bloom probes per key
     uint32_t span_chunks;     // 1-KiB chunks per span
     uint32_t dynamic;         // 1: waves draw spans from counters[4] instead of a static round-robin
+    uint32_t key_len;         // H: symbols per key (12..16); windows are H symbols, keys 2H bits
+    uint32_t key_mask;        // (1 << 2H) - 1
     uint32_t hash_variant;    // 0/1: Bloom cascade with mul / xor-shift hashes, 2: perfect-hash fingerprints
     uint32_t lds_words;       // size of the LDS image (bitmap, or fingerprint table + displacement table)
     uint32_t chd_slot_mask;   // fingerprint slots - 1
@@ -180,12 +183,14 @@ __device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
 
 // Level 1 + level 2 on NWD 2-bit-packed words per lane (w[j] = 16 bases, prev[j] = the 16 bases before them).
 // PK selects how word j maps to a text position (1-byte text vs. packed shadow).
-template <int S, int NWD, int HV, int SIG, bool PK>
+// KM: keys shorter than 16 symbols (masked); only strides 1 and 2 ever carry such keys.
+template <int S, int NWD, int HV, int SIG, bool PK, bool KM>
 __device__ __forceinline__ void filter_words(const filter_params &P, const uint32_t (&w)[NWD],
                                              const uint32_t (&prev)[NWD], const uint32_t (&nv)[SIG == 5 ? NWD : 1],
                                              uint64_t gbase, uint32_t lane, const uint32_t *lds, uint32_t idx_mask)
 {
     constexpr int NWIN = 16 / S; // windows per word
+    const uint32_t kmask = KM ? P.key_mask : 0xFFFFFFFFu;
     static_assert(NWD * NWIN <= 32, "one mask bit per window of a group");
     // windows d = S, 2S, .., 16 of chunk u: text start t = L_u - 16 + d, key = bits [2d, 2d+32) of (w:prev)
     uint32_t pos_mask = 0;
@@ -200,7 +205,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
-                const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                const uint32_t key = (d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31)) & kmask;
                 const uint32_t x = key * 0x9E3779B1u;
                 xs[u * NWIN + i] = x;
                 ds[u * NWIN + i] = disp_tab[x >> P.chd_bucket_shift];
@@ -211,7 +216,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
-                const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                const uint32_t key = (d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31)) & kmask;
                 const uint32_t slot = ((xs[u * NWIN + i] >> 3) + ds[u * NWIN + i] * ((key | 1u) & 0xFFFFFFu)) &
                                       P.chd_slot_mask;
                 ds[u * NWIN + i] = fp_tab[slot];
@@ -222,7 +227,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
-                const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                const uint32_t key = (d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31)) & kmask;
                 const uint32_t miss = (ds[u * NWIN + i] ^ key ^ (key >> 16)) & 0xFFFFu;
                 pos_mask |= (miss == 0 ? 1u : 0u) << (u * NWIN + i);
             }
@@ -233,7 +238,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 #pragma unroll
             for (int i = 0; i < NWIN; ++i) {
                 const int d = S * (i + 1);
-                const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                const uint32_t key = (d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31)) & kmask;
                 const uint32_t h = bloom_hash<HV>(key, 0) & idx_mask;
                 const uint32_t word = lds[h >> 5];
                 pos_mask |= __builtin_amdgcn_ubfe(word, h, 1) << (u * NWIN + i);
@@ -250,7 +255,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
                 for (int i = 0; i < NWIN; ++i) {
                     if (pos_mask & (1u << (u * NWIN + i))) {
                         const int d = S * (i + 1);
-                        const uint32_t key = d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31);
+                        const uint32_t key = (d == 16 ? w[u] : alignbit(w[u], prev[u], (2 * d) & 31)) & kmask;
                         const uint32_t h = bloom_hash<HV>(key, pr) & idx_mask;
                         const uint32_t word = lds[h >> 5];
                         keep |= __builtin_amdgcn_ubfe(word, h, 1) << (u * NWIN + i);
@@ -267,7 +272,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 #pragma unroll
                 for (int i = 0; i < NWIN; ++i) {
                     const int d = S * (i + 1);
-                    if (__builtin_amdgcn_ubfe(nv[u], d, 16) != 0) // an N inside the window
+                    if (__builtin_amdgcn_ubfe(nv[u], d, P.key_len) != 0) // an N inside the window
                         pos_mask &= ~(1u << (u * NWIN + i));
                 }
             }
@@ -293,13 +298,13 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
                     wu = w[q];
                     pu = prev[q];
                 }
-            key = d == 16 ? wu : alignbit(wu, pu, (uint32_t)(2 * d) & 31u);
+            key = (d == 16 ? wu : alignbit(wu, pu, (uint32_t)(2 * d) & 31u)) & kmask;
             // first base of word u of this lane: 1-byte text = chunk u, 16 bytes per lane; packed shadow = load u>>2
             // (4096 bases), 64 bases per lane, word u&3
             const uint64_t wpos = PK ? gbase + (uint64_t)(u >> 2) * 4096 + (uint64_t)lane * 64 + (uint64_t)(u & 3) * 16
                                      : gbase + (uint64_t)u * 1024 + (uint64_t)lane * 16;
             const int64_t ts = (int64_t)wpos - 16 + d;
-            if (ts >= (int64_t)P.lo && (uint64_t)ts + kKeyH <= P.hi) {
+            if (ts >= (int64_t)P.lo && (uint64_t)ts + P.key_len <= P.hi) {
                 t = (uint64_t)ts;
                 slot = ht_hash(key) & P.ht_mask;
                 probing = true;
@@ -345,7 +350,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 
 // One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
 // gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
-template <int S, int UU, int HV, int SIG>
+template <int S, int UU, int HV, int SIG, bool KM>
 __device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
                                              uint32_t &carry_in, uint32_t &carry_n, uint32_t lane,
                                              const uint32_t *lds, uint32_t idx_mask)
@@ -368,14 +373,14 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             nv[u] = (nm << 16) | np;
         }
     }
-    filter_words<S, UU, HV, SIG, false>(P, w, prev, nv, gbase, lane, lds, idx_mask);
+    filter_words<S, UU, HV, SIG, false, KM>(P, w, prev, nv, gbase, lane, lds, idx_mask);
 }
 
 // Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
 // (U KiB contiguous per wave) while the unconditional 16-byte loads of the next group are already in flight, so
 // each wave keeps 2*U KiB outstanding.  Only groups that lie fully inside the text take this path; the ragged end
 // of the text goes through a guarded one-chunk loop (bytes past the end read as 0).
-template <int S, int U, bool NT, int HV, int SIG>
+template <int S, int U, bool NT, int HV, int SIG, bool KM>
 __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
@@ -466,14 +471,14 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     nxt[u] = load16_stream<NT>(lane_text + pf * 1024 + (uint64_t)u * ustride);
-                filter_group<S, U, HV, SIG>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
+                filter_group<S, U, HV, SIG, KM>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
             }
         }
         // ---- ragged end ----
         for (; ch < c_end; ++ch) {
             uint4 one[1];
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
-            filter_group<S, 1, HV, SIG>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
+            filter_group<S, 1, HV, SIG, KM>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
         }
         sp += n_waves;
     }
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void text_pack_kernel(const uint8_t *__restric
 // Same filter, fed from the shadow: one 16-byte load per lane = 4 words = 64 symbols; a wave-load ("p-chunk") covers
 // 4096 symbols.  U2 p-chunks per group, the next group's loads in flight.  The shadow is zero-padded to whole
 // p-chunks, so every load is unconditional; windows reaching past the text are dropped by the range check.
-template <int S, int U2, int HV>
+template <int S, int U2, int HV, bool KM>
 __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_params P, const uint4 *__restrict__ shadow)
 {
     extern __shared__ uint32_t lds[];
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
                 prev[4 * u + 2] = cur[u].y;
                 prev[4 * u + 3] = cur[u].z;
             }
-            filter_words<S, NWD, HV, 4, true>(P, w, prev, nv, base0 + ch * 4096, lane, lds, idx_mask);
+            filter_words<S, NWD, HV, 4, true, KM>(P, w, prev, nv, base0 + ch * 4096, lane, lds, idx_mask);
         }
         sp += n_waves;
     }
@@ -617,7 +622,7 @@ struct verify_params
     uint32_t sigma;        // alphabet size; LDS holds sigma+1 rows per thread (row sigma = no match)
     uint32_t nw_table;     // words per needle in that table
     uint32_t max_k;        // largest k of the set: 2*max_k + 1 end-position slots per candidate
-    uint32_t pad3;
+    uint32_t key_len;      // symbols per key (a key window must lie inside one segment)
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                     hi = mid;
             }
             const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
-            if ((int64_t)c.t + (int64_t)kKeyH > se)
+            if ((int64_t)c.t + (int64_t)P.key_len > se)
                 continue; // the key window straddles two haystacks
             own_b = sb;
             own_e = se;

@@ -29,6 +29,7 @@ struct filter_index
 {
     bool ok = false;
     uint32_t stride = 0;
+    uint32_t key_len = 16;
     uint32_t bitmap_words = 0;
     uint32_t n_probes = 0;
     uint32_t hash_variant = 0;
@@ -70,6 +71,7 @@ struct spm_patterns
     int32_t *d_k = nullptr;
     std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
     uint32_t filter_stride = 0;
+    uint32_t filter_key_len = 16;
 };
 
 static uint32_t next_pow2(uint32_t x)
@@ -108,10 +110,19 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         qmin = std::min(qmin, m / (k + 1));
         n_seeds += k + 1;
     }
-    if (qmin < kKeyH)
+    if (qmin < kKeyMin)
         return SPM_OK;
+    // key length H and stride S: a window of H symbols at every S-th text position needs S <= q - H + 1.
+    // Seeds of >= 17 symbols use full 32-bit keys; shorter seeds give up one or two symbols of key for stride 2
+    // (half the windows), which costs far less than the extra spurious key matches it lets through.
+    uint32_t H = kKeyMax;
+    if (qmin < kKeyMax + 1)
+        H = qmin == kKeyMin ? kKeyMin : qmin - 1;
+    const int force_h = env_int("SPM_HIP_FILTER_KEYLEN", 0);
+    if (force_h >= (int)kKeyMin && force_h <= (int)std::min(qmin, kKeyMax))
+        H = (uint32_t)force_h;
     uint32_t Smax = 1;
-    while (Smax * 2 <= 16 && Smax * 2 <= qmin - (kKeyH - 1))
+    while (Smax * 2 <= 16 && Smax * 2 <= qmin - (H - 1))
         Smax *= 2;
     const int force_s = env_int("SPM_HIP_FILTER_STRIDE", 0);
     if (force_s > 0 && (uint32_t)force_s <= Smax)
@@ -134,6 +145,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
     }
     const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
     ps->filter_stride = S;
+    ps->filter_key_len = H;
     uint32_t p0 = 0;
     while (p0 < ps->n) {
         uint64_t keys = 0;
@@ -154,6 +166,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
             return SPM_OK; // too many passes to be worth it: brute force
         }
         filter_index F;
+        F.key_len = H;
         int rc = build_one_index(ctx, ps, p0, p1, S, F);
         if (rc != SPM_OK)
             return rc;
@@ -187,9 +200,9 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
         for (uint32_t j = 0; j <= k; ++j) {
             const uint32_t o = j * q;
             for (uint32_t r = 0; r < S; ++r) {
-                // window seed[r, r+16) -- inside the seed because S <= q - 15
+                // window seed[r, r+H) -- inside the seed because S <= q - H + 1
                 uint32_t key = 0;
-                for (uint32_t i = 0; i < kKeyH; ++i)
+                for (uint32_t i = 0; i < F.key_len; ++i)
                     key |= (uint32_t)((ps->sigma == 5 && pat[o + r + i] == 4) ? 3u : (pat[o + r + i] & 3u)) << (2 * i);
                 keys.push_back({key, (p << 11) | (o + r)});
             }
@@ -1083,6 +1096,8 @@ int run_filter(const scan_args &A)
     for (size_t fi = 0; fi < ps->fidx.size(); ++fi) {
     const filter_index &F = ps->fidx[fi];
     P.stride = F.stride;
+    P.key_len = F.key_len;
+    P.key_mask = F.key_len >= 16 ? 0xFFFFFFFFu : ((1u << (2 * F.key_len)) - 1);
     P.bitmap_words = F.hash_variant == 2 ? 1024 : F.bitmap_words;
     P.lds_words = F.lds_words;
     P.chd_slot_mask = F.chd_slot_mask;
@@ -1119,18 +1134,28 @@ int run_filter(const scan_args &A)
     const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
     const bool NT = env_int("SPM_HIP_FILTER_NT", 1) != 0;
     P.hash_variant = F.hash_variant;
+    const bool short_keys = F.key_len < 16;
+#define LAUNCH_FILTER4(S, UU, NTT, HV, SG, KM)                                                                         \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV, SG, KM>,                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_kernel<S, UU, NTT, HV, SG, KM>), dim3(grid), dim3(threads), lds, ctx->stream,  \
+                           P);                                                                                         \
+    } while (0)
+    // keys shorter than 16 symbols only occur with strides 1 and 2: the masked variants exist for those alone
 #define LAUNCH_FILTER3(S, UU, NTT, HV)                                                                                 \
     do {                                                                                                               \
+        constexpr bool km = (S) <= 2;                                                                                  \
         if (ps->sigma == 5) {                                                                                          \
-            hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, true, 2, 5>,                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-            hipLaunchKernelGGL((seed_filter_kernel<S, UU, true, 2, 5>), dim3(grid), dim3(threads), lds, ctx->stream,   \
-                               P);                                                                                     \
+            if (short_keys)                                                                                            \
+                LAUNCH_FILTER4(S, UU, true, 2, 5, km);                                                                 \
+            else                                                                                                       \
+                LAUNCH_FILTER4(S, UU, true, 2, 5, false);                                                              \
         } else {                                                                                                       \
-            hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV, 4>,                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-            hipLaunchKernelGGL((seed_filter_kernel<S, UU, NTT, HV, 4>), dim3(grid), dim3(threads), lds, ctx->stream,   \
-                               P);                                                                                     \
+            if (short_keys)                                                                                            \
+                LAUNCH_FILTER4(S, UU, NTT, HV, 4, km);                                                                 \
+            else                                                                                                       \
+                LAUNCH_FILTER4(S, UU, NTT, HV, 4, false);                                                              \
         }                                                                                                              \
     } while (0)
 #define LAUNCH_FILTER2(S, UU)                                                                                          \
@@ -1168,12 +1193,20 @@ int run_filter(const scan_args &A)
         Q.span_chunks = (uint32_t)pspan;
         Q.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (pspan >= 48 ? 1u : 2u);
         const uint4 *shadow = reinterpret_cast<const uint4 *>(A.text->d_packed);
+#define LAUNCH_PACKED2(S, U2, KM)                                                                                      \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_packed_kernel<S, U2, 2, KM>,                                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_packed_kernel<S, U2, 2, KM>), dim3(grid), dim3(threads), lds, ctx->stream, Q,  \
+                           shadow);                                                                                    \
+    } while (0)
 #define LAUNCH_PACKED(S, U2)                                                                                           \
     do {                                                                                                               \
-        hipFuncSetAttribute((const void *)seed_filter_packed_kernel<S, U2, 2>,                                         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-        hipLaunchKernelGGL((seed_filter_packed_kernel<S, U2, 2>), dim3(grid), dim3(threads), lds, ctx->stream, Q,      \
-                           shadow);                                                                                    \
+        constexpr bool km = (S) <= 2;                                                                                  \
+        if (short_keys)                                                                                                \
+            LAUNCH_PACKED2(S, U2, km);                                                                                 \
+        else                                                                                                           \
+            LAUNCH_PACKED2(S, U2, false);                                                                              \
     } while (0)
         switch (F.stride) {
         case 16: LAUNCH_PACKED(16, 4); break;
@@ -1186,6 +1219,7 @@ int run_filter(const scan_args &A)
             return SPM_E_UNSUPPORTED;
         }
 #undef LAUNCH_PACKED
+#undef LAUNCH_PACKED2
     } else
     switch (F.stride) {
     case 16: LAUNCH_FILTER(16, 8); break;
@@ -1196,6 +1230,7 @@ int run_filter(const scan_args &A)
     }
 #undef LAUNCH_FILTER2
 #undef LAUNCH_FILTER3
+#undef LAUNCH_FILTER4
 #undef LAUNCH_FILTER
     SPM_HIP_CHECK(ctx, hipGetLastError());
     H->stats.main_launches++;
@@ -1216,6 +1251,7 @@ int run_filter(const scan_args &A)
     V.sigma = ps->sigma;
     V.nw_table = ps->NW;
     V.max_k = ps->max_k;
+    V.key_len = ps->filter_key_len;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;
@@ -1591,7 +1627,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     if (rc != SPM_OK)
         return rc;
     stats[0] = ps.fidx.size();   // passes (0 = the seed filter does not apply)
-    stats[1] = ps.filter_stride; // S
+    stats[1] = ps.filter_stride | ((uint64_t)ps.filter_key_len << 32); // S | H << 32
     if (ps.fidx.empty())
         return SPM_OK;
     const uint32_t S = ps.filter_stride;
@@ -1640,7 +1676,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     uint64_t in_pass = 0;
     for (uint32_t p = 0; p < n_patterns; ++p) {
         const uint32_t m = (uint32_t)ps.m[p], kk = (uint32_t)ps.k[p], q = m / (kk + 1);
-        if (S > q - (kKeyH - 1))
+        if (S > q - (ps.filter_key_len - 1))
             return SPM_E_INVALID; // sampling would miss occurrences
         const uint64_t mine = (uint64_t)(kk + 1) * S;
         while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
@@ -1657,7 +1693,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
         for (uint32_t j = 0; j <= kk; ++j)
             for (uint32_t r = 0; r < S; ++r) {
                 uint32_t key = 0;
-                for (uint32_t i = 0; i < kKeyH; ++i) {
+                for (uint32_t i = 0; i < ps.filter_key_len; ++i) {
                     const uint8_t c = pat[j * q + r + i];
                     key |= (uint32_t)((sigma == 5 && c == 4) ? 3u : (c & 3u)) << (2 * i);
                 }
@@ -1672,7 +1708,10 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     uint64_t fp = 0;
     const uint64_t trials = 1 << 20;
     for (uint64_t t = 0; t < trials; ++t)
-        fp += level1(ps.fidx[0], (uint32_t)mix64(0xC0FFEE + t)) ? 1 : 0;
+        fp += level1(ps.fidx[0], (uint32_t)mix64(0xC0FFEE + t) &
+                                     (ps.filter_key_len >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ps.filter_key_len)) - 1)))
+                  ? 1
+                  : 0;
     stats[5] = fp;
     stats[6] = trials;
     stats[7] = ps.fidx[0].hash_variant;

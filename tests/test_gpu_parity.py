@@ -118,7 +118,10 @@ def _planted_config(spm, oracle, n_total, n_pat, L, kmax, seed_text=0x5EED0001, 
 
 
 @pytest.mark.parametrize("cfg", [("myers", 100, 3, 256), ("myers", 150, 3, 100), ("shiftor", 32, 0, 256),
-                                 ("myers", 64, 1, 64), ("myers", 1024, 10, 8)])
+                                 ("myers", 64, 1, 64), ("myers", 1024, 10, 8),
+                                 # short seeds -> keys of 12..15 symbols: q = 15 (the C5 shape), 16, 13, 12
+                                 ("myers", 1024, 64, 8), ("myers", 60, 3, 100), ("myers", 64, 3, 64),
+                                 ("myers", 52, 3, 64), ("myers", 48, 3, 64), ("shiftor", 13, 0, 40)])
 def test_filter_engine_equals_brute_and_oracle(spm, ctx, oracle, cfg):
     """Seed filter + verification must return exactly the brute-force hit set (and the oracle's)."""
     algo, L, kmax, n_pat = cfg

@@ -18,7 +18,10 @@ def _selftest(spm, algo, needles, k, sigma=4):
                                               offs.ctypes.data_as(C.POINTER(C.c_uint32)), len(needles),
                                               ks.ctypes.data_as(C.POINTER(C.c_uint16)), sigma, stats)
     names = ["passes", "stride", "keys", "checked", "missing", "fp", "trials", "hash_variant"]
-    return rc, dict(zip(names, [int(x) for x in stats]))
+    st = dict(zip(names, [int(x) for x in stats]))
+    st["key_len"] = st["stride"] >> 32
+    st["stride"] &= 0xFFFFFFFF
+    return rc, st
 
 
 def test_c3_shaped_set_single_pass_fingerprint_table(spm):
@@ -44,9 +47,16 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     # mixed lengths and k: the stride follows the shortest seed
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
-    assert rc == 0 and st["stride"] == 1 and st["passes"] == 1      # 64 / 4 = 16 -> only stride 1 fits
-    # seeds shorter than a key: the filter does not apply
-    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8)], 3)
+    assert rc == 0 and st["passes"] == 1 and (st["key_len"], st["stride"]) == (15, 2)   # q = 64 / 4 = 16
+    # short seeds: q = 15 (|P| = 60, k = 3 and the C5 shape |P| = 1024, k = 64) -> 14-symbol keys at stride 2
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8) for _ in range(100)], 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and (st["key_len"], st["stride"]) == (14, 2)
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 1024, dtype=np.uint8) for _ in range(64)], 64)
+    assert rc == 0 and st["missing"] == 0 and (st["key_len"], st["stride"]) == (14, 2)
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 48, dtype=np.uint8)], 3)      # q = 12
+    assert rc == 0 and st["missing"] == 0 and (st["key_len"], st["stride"]) == (12, 1)
+    # seeds shorter than the shortest key: the filter does not apply
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 44, dtype=np.uint8)], 3)
     assert rc == 0 and st["passes"] == 0
 
 
