@@ -39,6 +39,27 @@ WORKLOADS = {
 }
 
 
+VALU_PEAK_LANE_OPS = 6.5e13   # measured: v_add_u32 / v_bitop3_b32 chains, 8 waves per SIMD (tools/valu_probe.hip)
+VALU_NOMINAL_LANE_OPS = 256 * 128 * 2.4e9
+
+
+def valu_roofline(workload, n_pat, lane_steps_per_s):
+    """SURVEY 8(d)(ii) for the brute-force engine: lane-ops/s against the measured integer-VALU issue peak.
+
+    VALU instructions per lane-step come from a PMC pass over the same kernel (SQ_INSTS_VALU / wave-steps,
+    profiles/brute_valu.json, written by scripts/collect_profiles.py); None if that pass was never collected."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "brute_valu.json")))[workload]
+        if pm["needles"] != n_pat:
+            return None
+    except Exception:
+        return None
+    ops = lane_steps_per_s * pm["valu_per_lane_step"]
+    return {"kernel": pm["kernel"], "valu_per_lane_step": pm["valu_per_lane_step"], "lane_ops_per_s": ops,
+            "peak_measured": VALU_PEAK_LANE_OPS, "frac_of_measured": ops / VALU_PEAK_LANE_OPS,
+            "peak_nominal": VALU_NOMINAL_LANE_OPS}
+
+
 def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
     """The oracle (CPU restatement of the reference path: one matcher per needle, one pass per matcher) timed on
     the host cores, on a bounded sample of the same workload.  A reported baseline, not the target."""
@@ -232,6 +253,9 @@ def main():
                 "candidates": int(st.n_candidates),
                 "fell_back": int(st.fell_back),
                 "lane_steps_per_s": n_pat * n_total / (dt / args.steps),
+                # what the reference's traffic model (one full text pass PER needle) would have moved
+                # in the same time -- for comparison only, NOT a roofline figure
+                "reference_equivalent_traffic_GBps": n_pat * n_total / (dt / args.steps) / 1e9,
             }
 
         # brute-force engine (the one-lane-per-needle kernel) on a bounded slice, for reference next to the filter
@@ -246,6 +270,8 @@ def main():
                 "lane_steps_per_s": n_pat * nb / (sb.ms_main * 1e-3),
                 "sample_bytes": nb,
                 "hits_equal_to_default_engine": same,
+                # this engine is bounded by integer-VALU issue, not HBM
+                "valu": valu_roofline(args.workload, n_pat, n_pat * nb / (sb.ms_main * 1e-3)),
             }
             hb.close()
             hf.close()

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <libspm/hip/context.hpp>
+#include <libspm/seqan/container_adapter.hpp>
 #include <libspm/matcher/concept.hpp>
 #include <libspm/seqan/alphabet.hpp>
 
@@ -58,14 +59,9 @@ namespace detail
         if constexpr (std::ranges::sized_range<range_t>)
             v.reserve(std::ranges::size(r));
         for (auto && s : r)
-            v.push_back(static_cast<std::uint8_t>(static_cast<unsigned>(s)));
+            v.push_back(rank_byte(s));
         return v;
     }
-
-    // Contiguous ranges of 1-byte symbols are handed over without a host copy.
-    template <typename range_t>
-    concept byte_contiguous = std::ranges::contiguous_range<range_t> && std::ranges::sized_range<range_t> &&
-                              sizeof(std::ranges::range_value_t<range_t>) == 1;
 } // namespace detail
 
 template <typename derived_t>
@@ -120,9 +116,12 @@ public:
     template <std::ranges::viewable_range haystack_t, typename callback_t>
     void operator()(haystack_t && haystack, callback_t && callback) noexcept
     {
-        if constexpr (detail::byte_contiguous<haystack_t>) {
-            static_cast<derived_t *>(this)->run(reinterpret_cast<std::uint8_t const *>(std::ranges::data(haystack)),
-                                                std::ranges::size(haystack), callback);
+        // the adapter lends the view its rank buffer: zero-copy for contiguous 1-byte symbols, staged otherwise
+        // (the reference wraps the same view for seqan2::Finder, seqan_pattern_base.hpp:43-47)
+        if constexpr (requires { make_seqan_container(std::views::all(std::forward<haystack_t>(haystack))); }) {
+            auto const adapted = make_seqan_container(std::views::all(std::forward<haystack_t>(haystack)));
+            auto const ranks = adapted.ranks();
+            static_cast<derived_t *>(this)->run(ranks.data(), ranks.size(), callback);
         } else {
             std::vector<std::uint8_t> const ranks = detail::to_ranks(haystack);
             static_cast<derived_t *>(this)->run(ranks.data(), ranks.size(), callback);

@@ -50,4 +50,37 @@ with open(f"{dst}/c3_16GiB_pmc_SQ_{tag}.csv", "w") as g:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             print(k, round(sum(v) / len(v)))
+# brute engine: VALU wave-instructions per wave-step (= per lane-step) of the kernel that ran, 0.25 GiB slice
+brute = {}
+NB = 1 << 28
+for d, wl, n_pat, key in (("pmc_brute_c3", "c3", 1024, "c3"), ("pmc_brute_c3_full", "c3", 1024, "c3_full_width"),
+                          ("pmc_brute_c2", "c2", 1024, "c2")):
+    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    if not fs:
+        continue
+    rows = [r for r in csv.DictReader(open(fs[0])) if "brute_kernel" in r["Kernel_Name"] or "cutoff_kernel" in r["Kernel_Name"]]
+    agg = collections.defaultdict(list)
+    for r in rows:
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "SQ_INSTS_VALU" not in agg:
+        continue
+    valu = sum(agg["SQ_INSTS_VALU"]) / len(agg["SQ_INSTS_VALU"])
+    salu = sum(agg["SQ_INSTS_SALU"]) / len(agg["SQ_INSTS_SALU"])
+    wave_steps = (n_pat / 64) * NB
+    brute[key] = {"kernel": rows[0]["Kernel_Name"].split("(")[0].split("<")[0].replace("void spm_hip::", ""),
+                  "needles": n_pat, "sample_bytes": NB, "SQ_INSTS_VALU": valu, "SQ_INSTS_SALU": salu,
+                  "valu_per_lane_step": valu / wave_steps, "salu_per_wave_step": salu / wave_steps,
+                  "method": "rocprofv3 --pmc SQ_INSTS_VALU over bench.py --engine brute --text-gib 0.25; wave "
+                            "instructions / ((needles / 64) x text symbols); includes the tile warm-up columns"}
+    with open(f"{dst}/brute_{key}_pmc_{tag}.csv", "w") as g:
+        w = csv.writer(g)
+        w.writerow(["kernel", "counter", "value", "duration_ns"])
+        for r in rows:
+            w.writerow([r["Kernel_Name"].split("(")[0], r["Counter_Name"], r["Counter_Value"],
+                        int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+if brute:
+    json.dump(brute, open("profiles/brute_valu.json", "w"), indent=1)
+    print({k: round(v["valu_per_lane_step"], 2) for k, v in brute.items()})
+if os.path.exists(f"{src}/valu_probe.jsonl"):
+    shutil.copy(f"{src}/valu_probe.jsonl", f"{dst}/valu_probe_{tag}.jsonl")
 print(open(f"{dst}/c3_16GiB_kernel_stats_{tag}.csv").read()[:600])

@@ -34,4 +34,16 @@ cd /tmp && timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-
 cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/$OUT/pmc_sq -- $B3 > $R/$OUT/pmc_sq.log 2>&1
 cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $R/$OUT/pmc_sq2 -- $B3 > $R/$OUT/pmc_sq2.log 2>&1
 cd $R
+say "brute engine: VALU instructions per lane-step (PMC) + VALU issue peak"
+rm -rf $OUT/pmc_brute_c3 $OUT/pmc_brute_c3_full $OUT/pmc_brute_c2
+BB="--engine brute --text-gib 0.25 --steps 2 --warmup 1 --no-cpu-baseline --packed-steps 0"
+cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/pmc_brute_c3 -- python3 $R/bench.py $BB > $R/$OUT/pmc_brute_c3.log 2>&1
+export SPM_HIP_BRUTE_CUTOFF=0
+cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/pmc_brute_c3_full -- python3 $R/bench.py $BB > $R/$OUT/pmc_brute_c3_full.log 2>&1
+unset SPM_HIP_BRUTE_CUTOFF
+cd /tmp && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/pmc_brute_c2 -- python3 $R/bench.py --workload c2 $BB > $R/$OUT/pmc_brute_c2.log 2>&1
+cd $R
+[ -x tools/valu_probe ] || (cd tools && hipcc -O3 --offload-arch=gfx950 -o valu_probe valu_probe.hip)
+timeout -k 10 120 ./tools/valu_probe > $OUT/valu_probe.jsonl
+tail -3 $OUT/valu_probe.jsonl
 say "done"

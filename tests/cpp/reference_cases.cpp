@@ -22,6 +22,7 @@
 #include <libspm/matcher/shiftor_matcher.hpp>
 #include <libspm/matcher/shiftor_matcher_restorable.hpp>
 #include <libspm/seqan/alphabet.hpp>
+#include <libspm/seqan/container_adapter.hpp>
 
 using spm::operator""_dna4;
 using spm::operator""_dna5;
@@ -299,6 +300,57 @@ static void alphabet_cases()
     EXPECT_TRUE(std::ranges::equal(ends, std::vector<std::size_t>{5, 10}));
 }
 
+// The view adapter of container_adapter.hpp:23-100: container interface over a view + the rank buffer the C ABI takes.
+static void container_adapter_cases()
+{
+    auto whole = spm::make_seqan_container(std::views::all(haystack));
+    static_assert(decltype(whole)::zero_copy);
+    static_assert(std::same_as<decltype(whole), spm::seqan_container_t<std::views::all_t<sequence_t const &>>>);
+    static_assert(std::copyable<decltype(whole)> && std::default_initializable<decltype(whole)>);
+    EXPECT_EQ(whole.size(), haystack.size());
+    EXPECT_EQ(seqan2::length(whole), haystack.size());
+    EXPECT_TRUE(!whole.empty() && !seqan2::empty(whole));
+    EXPECT_TRUE(whole[9] == spm::dna4{'G'} && *whole.begin() == spm::dna4{'A'});
+    EXPECT_TRUE(std::ranges::equal(whole, haystack));
+    EXPECT_TRUE(static_cast<void const *>(whole.ranks().data()) == static_cast<void const *>(haystack.data())); // no copy
+    EXPECT_EQ(whole.ranks().size(), haystack.size());
+
+    decltype(whole) blank{};
+    EXPECT_TRUE(blank.empty() && blank.ranks().empty() && !blank.has_view());
+    spm::assign(blank, whole);
+    EXPECT_TRUE(blank.has_view() && blank.size() == haystack.size());
+
+    // a non-contiguous view is staged into rank bytes
+    auto reversed = spm::make_seqan_container(haystack | std::views::reverse);
+    static_assert(!decltype(reversed)::zero_copy);
+    EXPECT_EQ(reversed.size(), haystack.size());
+    EXPECT_TRUE(reversed[0] == haystack.back());
+    auto rr = reversed.ranks();
+    bool same = rr.size() == haystack.size();
+    for (std::size_t i = 0; same && i < rr.size(); ++i)
+        same = rr[i] == static_cast<std::uint8_t>(static_cast<unsigned>(haystack[haystack.size() - 1 - i]));
+    EXPECT_TRUE(same);
+
+    // matchers take such views directly: reversed haystack, reversed needle -> mirrored begin positions
+    auto rneedle = needle | std::views::reverse;
+    auto matcher = spm::shiftor_matcher{rneedle};
+    std::vector<std::size_t> begins{};
+    matcher(haystack | std::views::reverse, [&](auto const & finder) { begins.push_back(seqan2::beginPosition(finder)); });
+    std::vector<std::size_t> expected{};
+    for (std::size_t b : {31, 20, 9})
+        expected.push_back(haystack.size() - (b + needle.size()));
+    EXPECT_TRUE(std::ranges::equal(begins, expected));
+
+    // a transformed view (complement) over a subrange
+    auto complement = [](spm::dna4 c) { return spm::dna4{static_cast<std::uint8_t>(3 - static_cast<unsigned>(c))}; };
+    auto comp_hay = haystack | std::views::drop(4) | std::views::transform(complement);
+    auto comp_needle = needle | std::views::transform(complement);
+    auto cm = spm::myers_matcher{comp_needle, 0};
+    std::vector<std::size_t> ends{};
+    cm(comp_hay, [&](auto const & finder) { ends.push_back(seqan2::endPosition(finder)); });
+    EXPECT_TRUE(std::ranges::equal(ends, std::vector<std::size_t>{10, 21, 32}));
+}
+
 int main()
 {
     horspool_cases();
@@ -310,6 +362,7 @@ int main()
     pigeonhole_cases();
     batch_cases();
     alphabet_cases();
+    container_adapter_cases();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures;
 }
