@@ -28,6 +28,8 @@ typedef struct spm_ctx spm_ctx;           /* one device + one HIP stream */
 typedef struct spm_text spm_text;         /* haystack resident in HBM, one uint8 rank per symbol */
 typedef struct spm_patterns spm_patterns; /* compiled needle set: Peq / mask tables, seed index */
 typedef struct spm_hits spm_hits;         /* result of one scan */
+typedef struct spm_jst spm_jst;           /* journaled sequence tree: reference + alleles + coverage, resident in HBM */
+typedef struct spm_jst_hits spm_jst_hits; /* result of one search over all haplotypes */
 
 enum spm_status {
     SPM_OK = 0,
@@ -168,6 +170,76 @@ int spm_hip_hits_stats(const spm_hits *hits, spm_scan_stats *out);
 /* order-independent checksum: sum over hits of mix64(pos ^ pattern<<40 ^ score<<58), SURVEY.md 8(d) */
 uint64_t spm_hip_hits_checksum(spm_hits *hits);
 void spm_hip_hits_destroy(spm_hits *hits);
+
+/* ---- journaled-sequence (pan-genome) search, config C5 ----------------------------------------------------
+ * The reference only designs the journaled sequence (specs/journaled_sequence_class_diagram.drawio:7-298) and gives the
+ * matcher-side hooks a traverser needs (spm::window_size / capture / restore, matcher/concept.hpp:26-161).  The
+ * contract implemented here is SURVEY.md 8(f)-2: the hit set equals the union over haplotypes of a linear scan of each
+ * materialised haplotype, reported as (haplotype, position in haplotype coordinates).
+ *
+ * Device-side scheme: the reference axis is cut into blocks; (block, haplotype) pairs whose haplotype-local sequence
+ * plus window-1 symbols of left context are byte-identical are found by an exact allele-set signature, one
+ * representative of each is spelled out into a context buffer, the buffer is scanned as independent segments by the
+ * same kernels as spm_hip_scan_segments, and every hit is fanned out to the haplotypes sharing its context.
+ *
+ * Alleles: sorted by `pos` (ties keep the given order); allele i replaces reference[pos, pos + ref_len) by
+ * alt_pool[alt_off, alt_off + alt_len).  coverage: n_alleles x ceil(n_haplotypes / 64) words, bit h of row i set iff
+ * haplotype h carries allele i.  Two alleles that overlap on the reference (pos_j < pos_i + ref_len_i for i < j) must
+ * have disjoint coverage (multi-allelic sites); otherwise SPM_E_UNSUPPORTED.  At most 1024 haplotypes. */
+typedef struct spm_jst_allele {
+    uint64_t pos;
+    uint32_t ref_len;
+    uint32_t alt_len;
+    uint64_t alt_off;
+} spm_jst_allele;
+
+typedef struct spm_jst_hit {
+    uint64_t pos;       /* what the matcher reports (Myers: exclusive end; exact: begin), haplotype coordinates */
+    uint32_t haplotype;
+    uint32_t pattern;
+    int32_t score;
+    uint32_t reserved;
+} spm_jst_hit;
+
+typedef struct spm_jst_stats {
+    uint64_t haplotype_symbols; /* sum of haplotype lengths over the indexed blocks: what per-haplotype scans read */
+    uint64_t context_symbols;   /* symbols laid out in the context buffer (what the device streams per search) */
+    uint64_t contexts;          /* non-empty (block, haplotype) pairs */
+    uint64_t unique_contexts;
+    uint64_t n_blocks;
+    uint32_t block_len;
+    uint32_t window;
+    float ms_index;             /* build of the context index (once per window size) */
+    float ms_scan;              /* last search: segment scan incl. verification */
+    float ms_fanout;            /* last search: hit fan-out to haplotypes */
+    uint32_t engine_used;
+    uint32_t reserved;
+} spm_jst_stats;
+
+/* `reference` must stay alive as long as the tree (it is not copied). */
+int spm_hip_jst_create(spm_ctx *ctx, const spm_text *reference, const spm_jst_allele *alleles, uint64_t n_alleles,
+                       const uint8_t *alt_pool, uint64_t alt_pool_len, const uint64_t *coverage,
+                       uint32_t n_haplotypes, spm_jst **out);
+void spm_hip_jst_destroy(spm_jst *jst);
+uint64_t spm_hip_jst_haplotype_length(const spm_jst *jst, uint32_t haplotype);
+/* Symbols [begin, begin + n) of haplotype h (host walk over the allele table; for needles and tests). */
+int spm_hip_jst_extract(spm_jst *jst, uint32_t haplotype, uint64_t begin, uint64_t n, uint8_t *out);
+/* Build the context index for needle sets whose spm::window_size is <= window.  block_len = reference positions per
+ * block (0 = library default); only blocks [block_begin, block_end) are indexed (block_end = 0: all) -- the shard of
+ * one GPU when a tree is searched by several, SURVEY.md 8(e). */
+int spm_hip_jst_index(spm_jst *jst, uint32_t window, uint32_t block_len, uint64_t block_begin, uint64_t block_end);
+int spm_hip_jst_search(spm_jst *jst, const spm_patterns *patterns, const spm_scan_opts *opts, spm_jst_hits **out);
+int spm_hip_jst_stats(const spm_jst *jst, spm_jst_stats *out);
+/* Host view sorted by (haplotype, pos, pattern); device view in arrival order (for an RCCL gather). */
+int spm_hip_jst_hits_view(spm_jst_hits *hits, const spm_jst_hit **records, uint64_t *n);
+int spm_hip_jst_hits_device(spm_jst_hits *hits, const void **device_records, uint64_t *n);
+void spm_hip_jst_hits_destroy(spm_jst_hits *hits);
+/* Synthetic variants of config C5: one SNP per 1000 reference bases, one indel of length 1..50 per
+ * 10 000, each carried by a random non-empty subset of n_haplotypes <= 64; the reference is the synthetic text of
+ * `seed_text`.  Call with alleles == NULL to get the counts (*n_alleles, *alt_pool_len) first.  Host side. */
+int spm_hip_jst_synth_variants(uint64_t seed_text, uint64_t seed_var, uint64_t ref_begin, uint64_t n_ref,
+                               uint32_t n_haplotypes, spm_jst_allele *alleles, uint64_t *n_alleles, uint8_t *alt_pool,
+                               uint64_t *alt_pool_len, uint64_t *coverage);
 
 /* ---- synthetic needles of the benchmark configs (host side) -------------------------- */
 uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,

@@ -51,6 +51,32 @@ class ScanStats(C.Structure):
     ]
 
 
+class JstAllele(C.Structure):
+    _fields_ = [("pos", C.c_uint64), ("ref_len", C.c_uint32), ("alt_len", C.c_uint32), ("alt_off", C.c_uint64)]
+
+
+class JstHit(C.Structure):
+    _fields_ = [("pos", C.c_uint64), ("haplotype", C.c_uint32), ("pattern", C.c_uint32), ("score", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+class JstStats(C.Structure):
+    _fields_ = [
+        ("haplotype_symbols", C.c_uint64),
+        ("context_symbols", C.c_uint64),
+        ("contexts", C.c_uint64),
+        ("unique_contexts", C.c_uint64),
+        ("n_blocks", C.c_uint64),
+        ("block_len", C.c_uint32),
+        ("window", C.c_uint32),
+        ("ms_index", C.c_float),
+        ("ms_scan", C.c_float),
+        ("ms_fanout", C.c_float),
+        ("engine_used", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
 def build(force: bool = False) -> str:
     """Compile libspm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
@@ -108,6 +134,20 @@ def lib():
         "spm_hip_mix64": (C.c_uint64, [C.c_uint64]),
         "spm_hip_host_selftest": (C.c_int, [C.c_int, u8p, u32p, C.c_uint32, u16p, C.c_uint32, C.POINTER(C.c_uint64)]),
         "spm_hip_version": (C.c_char_p, []),
+        "spm_hip_jst_create": (C.c_int, [vp, vp, C.POINTER(JstAllele), C.c_uint64, u8p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(vp)]),
+        "spm_hip_jst_destroy": (None, [vp]),
+        "spm_hip_jst_haplotype_length": (C.c_uint64, [vp, C.c_uint32]),
+        "spm_hip_jst_extract": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
+        "spm_hip_jst_index": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64]),
+        "spm_hip_jst_search": (C.c_int, [vp, vp, C.POINTER(ScanOpts), C.POINTER(vp)]),
+        "spm_hip_jst_stats": (C.c_int, [vp, C.POINTER(JstStats)]),
+        "spm_hip_jst_hits_view": (C.c_int, [vp, C.POINTER(C.POINTER(JstHit)), C.POINTER(C.c_uint64)]),
+        "spm_hip_jst_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "spm_hip_jst_hits_destroy": (None, [vp]),
+        "spm_hip_jst_synth_variants": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                 C.POINTER(JstAllele), C.POINTER(C.c_uint64), u8p,
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -126,4 +166,7 @@ EXPORTS = [
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
     "spm_hip_hits_copy_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
     "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
+    "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
+    "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",
+    "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",
 ]

@@ -865,6 +865,8 @@ struct scan_args
     spm_hits *hits;
     const uint64_t *seg_offsets = nullptr; // host; n_segments + 1 entries
     uint64_t n_segments = 0;
+    const uint64_t *d_seg_offsets = nullptr; // the same table already resident on the device (journaled-sequence index)
+    std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
 };
 
 template <int NW>
@@ -1004,6 +1006,15 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
         tile = 4;
     P.tile = (uint32_t)std::min<uint64_t>(tile, 0xFFFFFF00u);
     P.n_tiles = (uint32_t)std::max<uint64_t>(1, (range + P.tile - 1) / P.tile);
+    if (!A.seg_offsets && A.d_seg_offsets) {
+        // brute-force run over a device-resident segment table (fallback of the journaled-sequence search)
+        scan_args &W = const_cast<scan_args &>(A);
+        W.seg_host.resize(A.n_segments + 1);
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(W.seg_host.data(), A.d_seg_offsets, (A.n_segments + 1) * sizeof(uint64_t),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        W.seg_offsets = W.seg_host.data();
+    }
     if (A.seg_offsets) {
         // every segment is its own haystack: tiles never cross a segment, warm-up stays inside it
         std::vector<uint64_t> tab;
@@ -1261,7 +1272,10 @@ int run_filter(const scan_args &A)
     V.hit_counter = H->d_count;
     V.hit_cap = H->cap;
     V.overflow = H->d_count + 2;
-    if (A.seg_offsets) {
+    if (A.d_seg_offsets) {
+        V.seg_offsets = A.d_seg_offsets;
+        V.n_segments = A.n_segments;
+    } else if (A.seg_offsets) {
         uint64_t *d_seg = nullptr;
         SPM_HIP_CHECK(ctx, hipMalloc(&d_seg, (A.n_segments + 1) * sizeof(uint64_t)));
         hipFree(H->d_aux[1]);
@@ -1285,7 +1299,7 @@ int run_filter(const scan_args &A)
 
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
-                     uint64_t n_segments, spm_hits **out);
+                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets = nullptr);
 
 extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end,
                             const spm_patterns *patterns, const spm_scan_opts *opts_in, const void *state_in,
@@ -1317,7 +1331,7 @@ extern "C" int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const u
 
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
-                     uint64_t n_segments, spm_hits **out)
+                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets)
 {
     if (!ctx || !text || !patterns || !out || begin > end || end > text->n) {
         SPM_SET_ERR(ctx, "spm_hip_scan: invalid argument");
@@ -1361,6 +1375,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
     A.seg_offsets = seg_offsets;
     A.n_segments = n_segments;
+    A.d_seg_offsets = d_seg_offsets;
 
     const bool has_state = state_in != nullptr;
     const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && !patterns->fidx.empty());
@@ -1719,3 +1734,5 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
 }
 
 extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.1 (gfx950)"; }
+
+#include "jst.hpp"

@@ -235,3 +235,91 @@ def synth_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, k
     o = capi.lib().spm_hip_synth_pattern(seed_text, seed_pat, n_total, p, L, kmax,
                                          out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out, int(o)
+
+
+ALLELE_DTYPE = np.dtype([("pos", "<u8"), ("ref_len", "<u4"), ("alt_len", "<u4"), ("alt_off", "<u8")])
+JST_HIT_DTYPE = np.dtype([("pos", "<u8"), ("haplotype", "<u4"), ("pattern", "<u4"), ("score", "<i4"),
+                          ("reserved", "<u4")])
+
+
+def synth_variants(seed_text: int, seed_var: int, ref_begin: int, n_ref: int, n_haplotypes: int):
+    """The synthetic variants of config C5: (alleles, alt_pool, coverage) as numpy arrays."""
+    na, npool = C.c_uint64(0), C.c_uint64(0)
+    rc = capi.lib().spm_hip_jst_synth_variants(seed_text, seed_var, ref_begin, n_ref, n_haplotypes, None, C.byref(na),
+                                               None, C.byref(npool), None)
+    if rc != 0:
+        raise capi.SpmError("spm_hip_jst_synth_variants: invalid argument")
+    alleles = np.zeros(max(1, na.value), dtype=ALLELE_DTYPE)
+    pool = np.zeros(max(1, npool.value), dtype=np.uint8)
+    cov = np.zeros(max(1, na.value), dtype=np.uint64)
+    rc = capi.lib().spm_hip_jst_synth_variants(seed_text, seed_var, ref_begin, n_ref, n_haplotypes,
+                                               alleles.ctypes.data_as(C.POINTER(capi.JstAllele)), C.byref(na),
+                                               pool.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(npool),
+                                               cov.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise capi.SpmError("spm_hip_jst_synth_variants failed")
+    return alleles[:na.value], pool[:npool.value], cov[:na.value]
+
+
+class Jst:
+    """Journaled sequence tree in HBM: a reference Text + alleles + per-allele haplotype coverage."""
+
+    def __init__(self, ctx: Context, reference: Text, alleles, alt_pool, coverage, n_haplotypes: int):
+        self.ctx, self.reference, self.n_haplotypes = ctx, reference, n_haplotypes
+        al = np.ascontiguousarray(alleles, dtype=ALLELE_DTYPE)
+        pool = np.ascontiguousarray(alt_pool, dtype=np.uint8)
+        cw = (n_haplotypes + 63) // 64
+        cov = np.ascontiguousarray(coverage, dtype=np.uint64).reshape(-1)
+        if cov.size != len(al) * cw:
+            raise ValueError("coverage must hold ceil(n_haplotypes / 64) words per allele")
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_jst_create(ctx._h, reference._h, al.ctypes.data_as(C.POINTER(capi.JstAllele)),
+                                             len(al), pool.ctypes.data_as(C.POINTER(C.c_uint8)), pool.size,
+                                             cov.ctypes.data_as(C.POINTER(C.c_uint64)), n_haplotypes, C.byref(h)),
+               ctx._h)
+        self._h = h
+
+    def haplotype_length(self, h: int) -> int:
+        return int(capi.lib().spm_hip_jst_haplotype_length(self._h, h))
+
+    def extract(self, h: int, begin: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint8)
+        _check(capi.lib().spm_hip_jst_extract(self._h, h, begin, n, out.ctypes.data_as(C.POINTER(C.c_uint8))),
+               self.ctx._h)
+        return out
+
+    def index(self, window: int, block_len: int = 0, block_begin: int = 0, block_end: int = 0):
+        _check(capi.lib().spm_hip_jst_index(self._h, window, block_len, block_begin, block_end), self.ctx._h)
+        return self.stats()
+
+    def stats(self) -> capi.JstStats:
+        st = capi.JstStats()
+        _check(capi.lib().spm_hip_jst_stats(self._h, C.byref(st)), self.ctx._h)
+        return st
+
+    def search(self, pats: PatternSet, *, engine: int = capi.ENGINE_AUTO, max_hits: int = 0) -> np.ndarray:
+        """All hits over all haplotypes, sorted by (haplotype, pos, pattern): JST_HIT_DTYPE records."""
+        opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, flags=0, reserved=0)
+        hh = C.c_void_p()
+        _check(capi.lib().spm_hip_jst_search(self._h, pats._h, C.byref(opts), C.byref(hh)), self.ctx._h)
+        try:
+            rec = C.POINTER(capi.JstHit)()
+            n = C.c_uint64(0)
+            _check(capi.lib().spm_hip_jst_hits_view(hh, C.byref(rec), C.byref(n)), self.ctx._h)
+            if n.value == 0:
+                return np.zeros(0, dtype=JST_HIT_DTYPE)
+            buf = (capi.JstHit * n.value).from_address(C.addressof(rec.contents))
+            return np.frombuffer(buf, dtype=JST_HIT_DTYPE).copy()
+        finally:
+            capi.lib().spm_hip_jst_hits_destroy(hh)
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_jst_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
