@@ -36,7 +36,11 @@ WORKLOADS = {
     "c3": ("myers", 100, 3, 1024, 16.0, "Myers k<=3, 1024 needles |P|=100, 16 GiB dna4 text per GPU"),
     "c2": ("shiftor", 32, 0, 1024, 1.0, "Shift-Or exact, 1024 needles |P|=32, 1 GiB dna4 text per GPU"),
     "c4": ("myers", 150, 3, 100000, 8.0, "Myers k<=3, 100k needles |P|=150, 8 GiB dna4 text per GPU (64 GiB on 8)"),
+    # journaled-sequence pan-genome: text GiB = REFERENCE bases per GPU (2^27; 2^30 on 8), 64 haplotypes over it
+    "c5": ("myers", 1024, 64, 256, 0.125, "multi-word Myers |P|=1024 k<=64, 256 needles, journaled pan-genome: "
+                                          "64 haplotypes over a 2^27-base reference per GPU (2^30 on 8)"),
 }
+SEED_VAR = 0x5EED0003
 
 
 VALU_PEAK_LANE_OPS = 6.5e13   # measured: v_add_u32 / v_bitop3_b32 chains, 8 waves per SIMD (tools/valu_probe.hip)
@@ -58,6 +62,197 @@ def valu_roofline(workload, n_pat, lane_steps_per_s):
     return {"kernel": pm["kernel"], "valu_per_lane_step": pm["valu_per_lane_step"], "lane_ops_per_s": ops,
             "peak_measured": VALU_PEAK_LANE_OPS, "frac_of_measured": ops / VALU_PEAK_LANE_OPS,
             "peak_nominal": VALU_NOMINAL_LANE_OPS}
+
+
+def edit_needle(src, L, e, seed):
+    """Needle of length L from src (>= L + e symbols): e edits at pseudo-random places (substitute / delete / insert),
+    trimmed back to L -- the scheme of SURVEY 8(d), applied to a haplotype window."""
+    import libspm_amd as S
+    out = [int(x) for x in src[:L + e]]
+    for j in range(e):
+        r = S.capi.lib().spm_hip_mix64(seed + j + 1)
+        at = r % L
+        kind = (r >> 32) % 3
+        if kind == 0:
+            out[at] = (out[at] + 1 + (r >> 40) % 3) & 3
+        elif kind == 1:
+            del out[at]
+        else:
+            out.insert(at, (r >> 40) & 3)
+    return np.array(out[:L], dtype=np.uint8)
+
+
+def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
+    """Config C5: needles against every haplotype of a journaled sequence tree.  One reference
+    chromosome per GPU (weak scaling), its context index built once on the device; a step = one search of the whole
+    needle set over all haplotypes (segment scan of the context buffer + verification + fan-out) + the gatherv."""
+    algo, L, kmax, n_pat, gib, desc = WORKLOADS["c5"]
+    if args.text_gib is not None:
+        gib = args.text_gib
+    if args.needles is not None:
+        n_pat = args.needles
+    n_hap = 64
+    ref_len = int(gib * 2**30) // 10000 * 10000
+    engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
+    mix = S.capi.lib().spm_hip_mix64
+    ref = ctx.generate(SEED_TEXT, rank * ref_len, ref_len)
+    t0 = time.perf_counter()
+    alleles, pool, cov = S.synth_variants(SEED_TEXT, SEED_VAR, rank * ref_len, ref_len, n_hap)
+    jst = S.Jst(ctx, ref, alleles, pool, cov.reshape(-1, 1), n_hap)
+    t_create = time.perf_counter() - t0
+    window = L + kmax
+
+    # needles: p is cut from chromosome p % world, haplotype mix(p) % 64, with p % (kmax + 1) edits; every rank
+    # spells out its own and the set is completed with one all-reduce (setup, not timed)
+    mine = np.zeros((n_pat, L), dtype=np.int32)
+    planted = {}
+    for p in range(rank, n_pat, world):
+        r = mix(SEED_PAT + 7919 * p)
+        h = r % n_hap
+        o = (r >> 8) % (jst.haplotype_length(h) - 2 * (L + kmax))
+        e = p % (kmax + 1)
+        mine[p] = edit_needle(jst.extract(h, o, L + kmax), L, e, SEED_PAT ^ (p << 20))
+        planted[p] = (h, o, e)
+    if world > 1:
+        t = torch.from_numpy(mine)
+        if dist.get_backend() != "gloo":
+            t = t.to(dev)
+        dist.all_reduce(t)
+        mine = t.cpu().numpy()
+    needles = [mine[p].astype(np.uint8) for p in range(n_pat)]
+    ps = ctx.patterns(S.ALGO_MYERS, needles, k=kmax)
+
+    # engines agree on a slice of the tree (the brute-force engine is too slow for all of it)
+    check = None
+    if rank == 0 and args.brute_sample_mib > 0:
+        jst.index(window, 1024, 0, 2048)
+        a = jst.search(ps, engine=engine, max_hits=1 << 22)
+        b = jst.search(ps, engine=S.ENGINE_BRUTE, max_hits=1 << 22)
+        check = {"blocks": 2048, "hits": int(len(a)), "hits_equal_to_default_engine": bool(np.array_equal(a, b))}
+    st = jst.index(window, 1024)
+    max_hits = 1 << 23
+    cap = max_hits
+    hit_buf = torch.zeros((cap, 3), dtype=torch.int64, device=dev)
+
+    def step():
+        h = jst.search_device(ps, engine=engine, max_hits=max_hits)
+        n = h.copy_to(hit_buf.data_ptr(), cap)
+        gathered = sdist.gatherv_hits(hit_buf[:n])      # rank 0: every rank's records, rank order
+        return h, gathered, n
+
+    for _ in range(args.warmup):
+        h, g, n = step()
+        h.close()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_main = ms_verify = ms_fan = 0.0
+    launches = 0
+    last = None
+    for _ in range(args.steps):
+        h, g, n = step()
+        s1 = jst.stats()
+        ms_main += s1.ms_main
+        ms_verify += s1.ms_verify
+        ms_fan += s1.ms_fanout
+        launches += s1.main_launches
+        if last is not None:
+            last[0].close()
+        last = (h, g, n, s1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    h, gathered, n_local, s1 = last
+    # every planted needle must be reported on its source haplotype where it was cut
+    rec = h.view()
+    h.close()
+    found = 0
+    by_needle = {}
+    for q in np.nonzero(np.isin(rec["pattern"], list(planted)))[0] if planted else []:
+        by_needle.setdefault(int(rec["pattern"][q]), []).append((int(rec["haplotype"][q]), int(rec["pos"][q]),
+                                                                 int(rec["score"][q])))
+    for p, (hh, o, e) in planted.items():
+        if any(a == hh and abs(b - (o + L)) <= kmax and c <= e for a, b, c in by_needle.get(p, [])):
+            found += 1
+    tot = torch.tensor([found, int(st.haplotype_symbols), int(st.context_symbols), int(st.unique_contexts),
+                        int(st.contexts)], dtype=torch.int64, device=dev)
+    if world > 1:
+        if dist.get_backend() == "gloo":
+            tc = tot.cpu()
+            dist.all_reduce(tc)
+            tot = tc
+        else:
+            dist.all_reduce(tot)
+    found, hap_sym, ctx_sym, uniq, nctx = [int(x) for x in tot.tolist()]
+    if rank != 0:
+        return None
+    step_s = dt / args.steps
+    k_ms = ms_main / max(launches, 1)
+    engine_used = {1: "brute", 2: "filter"}.get(int(s1.engine_used), "?")
+    achieved = st.context_symbols / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    result = {
+        "metric": "Gbases/s of haplotype sequence searched, multi-word Myers |P|=1024 k<=64 over a journaled pan-genome",
+        "value": hap_sym / step_s / 1e9,
+        "unit": "Gbases/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"c5: {desc}", "needles": n_pat, "needle_len": L, "k": kmax, "haplotypes": n_hap,
+                   "reference_bases_per_gpu": ref_len, "alleles_per_gpu": int(len(alleles)), "block_len": 1024,
+                   "engine": engine_used,
+                   "sharding": (f"one reference chromosome per GPU, {world} GPUs; hit records gathered to rank 0 "
+                                "(count all-gather + grouped send/recv)") if world > 1 else "single GPU"},
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_cutoff_kernel",
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": int(st.context_symbols),
+            "note": "algorithmic bytes = the deduplicated context buffer this GPU streams per search (1 byte per "
+                    "symbol); the haplotype symbols it stands for are `value`",
+        },
+        "hits": int(gathered.shape[0]) if gathered is not None else int(n_local),
+        "needles_found_on_their_haplotype": found,
+        "all_planted_found": bool(found == n_pat),
+        "journaled_sequence_tree": {
+            "haplotype_symbols": hap_sym, "context_symbols": ctx_sym, "sharing": hap_sym / max(ctx_sym, 1),
+            "contexts": nctx, "unique_contexts": uniq, "index_ms_rank0": st.ms_index, "create_s_rank0": t_create,
+            "segment_hits_rank0": int(s1.segment_hits),
+            "reference_Gbases_per_s": ref_len * world / step_s / 1e9,
+            "context_Gbases_per_s": ctx_sym / step_s / 1e9,
+        },
+        "verify_ms_per_step": ms_verify / args.steps,
+        "fanout_ms_per_step": ms_fan / args.steps,
+        "candidates": int(s1.candidates),
+        "fell_back": int(s1.fell_back),
+        "lane_steps_per_s": n_pat * hap_sym / step_s,
+        "reference_equivalent_traffic_GBps": n_pat * hap_sym / step_s / 1e9,
+    }
+    if check is not None:
+        result["brute_force_engine"] = check
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline("myers", L, kmax, n_pat, ref_len)
+        except Exception as e:
+            result["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port",
+                                      "sample": f"unavailable: {e}"}
+    return result
 
 
 def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
@@ -147,6 +342,13 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = S.Context(local_rank, stream=stream.cuda_stream)
+        if args.workload == "c5":
+            result = run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx)
+            if rank == 0:
+                print(json.dumps(result))
+            if world > 1:
+                dist.destroy_process_group()
+            return
         text = ctx.generate(SEED_TEXT, lo - ovl, (hi - lo) + ovl)
         needles = [S.synth_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(n_pat)]
         s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR

@@ -211,9 +211,14 @@ typedef struct spm_jst_stats {
     uint32_t window;
     float ms_index;             /* build of the context index (once per window size) */
     float ms_scan;              /* last search: segment scan incl. verification */
+    float ms_main;              /* last search: the scan's main kernel(s) (seed filter / brute force) */
+    float ms_verify;            /* last search: verification of the filter's candidates */
     float ms_fanout;            /* last search: hit fan-out to haplotypes */
     uint32_t engine_used;
-    uint32_t reserved;
+    uint32_t main_launches;
+    uint32_t fell_back;         /* last search: 1 if the seed filter overflowed and the brute engine re-ran the scan */
+    uint64_t segment_hits;      /* last search: hits in context coordinates, before the fan-out */
+    uint64_t candidates;        /* last search: seed-filter candidates verified */
 } spm_jst_stats;
 
 /* `reference` must stay alive as long as the tree (it is not copied). */
@@ -233,6 +238,8 @@ int spm_hip_jst_stats(const spm_jst *jst, spm_jst_stats *out);
 /* Host view sorted by (haplotype, pos, pattern); device view in arrival order (for an RCCL gather). */
 int spm_hip_jst_hits_view(spm_jst_hits *hits, const spm_jst_hit **records, uint64_t *n);
 int spm_hip_jst_hits_device(spm_jst_hits *hits, const void **device_records, uint64_t *n);
+/* Copy the first min(n, cap) records into a caller-owned device buffer, asynchronously on the context's stream. */
+int spm_hip_jst_hits_copy_device(spm_jst_hits *hits, void *device_dst, uint64_t cap, uint64_t *n);
 void spm_hip_jst_hits_destroy(spm_jst_hits *hits);
 /* Synthetic variants of config C5: one SNP per 1000 reference bases, one indel of length 1..50 per
  * 10 000, each carried by a random non-empty subset of n_haplotypes <= 64; the reference is the synthetic text of

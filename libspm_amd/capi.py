@@ -71,9 +71,14 @@ class JstStats(C.Structure):
         ("window", C.c_uint32),
         ("ms_index", C.c_float),
         ("ms_scan", C.c_float),
+        ("ms_main", C.c_float),
+        ("ms_verify", C.c_float),
         ("ms_fanout", C.c_float),
         ("engine_used", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("main_launches", C.c_uint32),
+        ("fell_back", C.c_uint32),
+        ("segment_hits", C.c_uint64),
+        ("candidates", C.c_uint64),
     ]
 
 
@@ -144,6 +149,7 @@ def lib():
         "spm_hip_jst_stats": (C.c_int, [vp, C.POINTER(JstStats)]),
         "spm_hip_jst_hits_view": (C.c_int, [vp, C.POINTER(C.POINTER(JstHit)), C.POINTER(C.c_uint64)]),
         "spm_hip_jst_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "spm_hip_jst_hits_copy_device": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         "spm_hip_jst_hits_destroy": (None, [vp]),
         "spm_hip_jst_synth_variants": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                                  C.POINTER(JstAllele), C.POINTER(C.c_uint64), u8p,
@@ -168,5 +174,5 @@ EXPORTS = [
     "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
     "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",
-    "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",
+    "spm_hip_jst_hits_copy_device", "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",
 ]

@@ -752,18 +752,22 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                     // dedupe across the seeds of one occurrence
                     const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
                     uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-                    for (uint32_t tries = 0; tries <= P.seen_mask; ++tries) {
+                    // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means
+                    // more hits than the caller's buffer takes: flag it, the host re-runs with the brute engine
+                    bool placed = false;
+                    for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
                         const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
                         if (old == ~0ull) {
                             fresh = true;
-                            break;
+                            placed = true;
+                        } else if (old == key) {
+                            placed = true;
+                        } else {
+                            slot = (slot + 1) & P.seen_mask;
                         }
-                        if (old == key)
-                            break;
-                        slot = (slot + 1) & P.seen_mask;
-                        if (tries == P.seen_mask)
-                            atomicAdd(P.overflow, 1ull);
                     }
+                    if (!placed)
+                        atomicAdd(P.overflow, 1ull);
                 }
                 if (__ballot(fresh) != 0)
                     wave_append_hits(fresh, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,

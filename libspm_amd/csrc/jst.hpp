@@ -929,7 +929,13 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
     spm_scan_stats ss{};
     spm_hip_hits_stats(seg, &ss);
     J->stats.ms_scan = ss.ms_total;
+    J->stats.ms_main = ss.ms_main;
+    J->stats.ms_verify = ss.ms_verify;
     J->stats.engine_used = ss.engine_used;
+    J->stats.main_launches = ss.main_launches;
+    J->stats.segment_hits = n_seg_hits;
+    J->stats.fell_back = ss.fell_back;
+    J->stats.candidates = ss.n_candidates;
     unsigned long long *d_count = nullptr;
     SPM_HIP_CHECK(ctx, hipMalloc(&R->d, out_cap * sizeof(spm_jst_hit)));
     SPM_HIP_CHECK(ctx, hipMalloc(&d_count, 8));
@@ -1008,6 +1014,18 @@ extern "C" int spm_hip_jst_hits_device(spm_jst_hits *h, const void **device_reco
         return SPM_E_INVALID;
     *device_records = h->d;
     *n = h->n;
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_jst_hits_copy_device(spm_jst_hits *h, void *device_dst, uint64_t cap, uint64_t *n)
+{
+    if (!h || !n || (cap && !device_dst))
+        return SPM_E_INVALID;
+    *n = h->n;
+    const uint64_t c = std::min(h->n, cap);
+    if (c)
+        SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(device_dst, h->d, c * sizeof(spm_jst_hit), hipMemcpyDeviceToDevice,
+                                             h->ctx->stream));
     return SPM_OK;
 }
 

@@ -6,6 +6,7 @@
 //   * choose engine, tile the haystack, launch, collect hits       -- the find loop
 // MI355X only; no CPU scan path exists in this library: if HIP fails the call fails.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -70,6 +71,7 @@ struct spm_patterns
     int32_t *d_m = nullptr;
     int32_t *d_k = nullptr;
     std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
+    mutable uint64_t cand_hint = 0; // most candidates a filter scan of this set has produced so far
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
 };
@@ -866,6 +868,7 @@ struct scan_args
     const uint64_t *seg_offsets = nullptr; // host; n_segments + 1 entries
     uint64_t n_segments = 0;
     const uint64_t *d_seg_offsets = nullptr; // the same table already resident on the device (journaled-sequence index)
+    uint64_t cand_cap_override = 0;          // retry after a candidate overflow: the count the first attempt needed
     std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
 };
 
@@ -1074,15 +1077,23 @@ int run_filter(const scan_args &A)
     spm_hits *H = A.hits;
     // scratch: candidates + dedupe set
     const uint64_t kmax = ps->max_k;
-    uint64_t seen_slots = 1u << 20;
-    uint64_t cand_cap = (seen_slots / 2) / (2 * kmax + 1);
-    cand_cap = std::max<uint64_t>(cand_cap, 1024);
-    // every needle is expected to contribute a handful of true seed hits: scale with the set
-    cand_cap = std::max<uint64_t>(cand_cap, 8ull * ps->n * (kmax + 1));
+    constexpr uint64_t kCandMax = 1ull << 25; // 512 MiB of candidates: beyond that the brute engine takes over
+    uint64_t cand_cap = std::max<uint64_t>(4096, 8ull * ps->n * (kmax + 1)); // a handful of true seed hits per needle
+    // chance hits of short keys: windows looked at x keys / 4^key_len, per pass (negligible for 16-symbol keys)
+    double chance = 0;
+    for (const filter_index &F : ps->fidx)
+        chance += (double)(A.end - A.begin) / std::max(1u, F.stride) * (double)F.n_keys / std::pow(4.0, (double)F.key_len);
+    cand_cap = std::max<uint64_t>(cand_cap, (uint64_t)(2.0 * chance));
+    cand_cap = std::max<uint64_t>(cand_cap, ps->cand_hint + ps->cand_hint / 4);
+    cand_cap = std::min(cand_cap, kCandMax);
+    if (A.cand_cap_override)
+        cand_cap = A.cand_cap_override;
     const int cc = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
     if (cc > 0)
         cand_cap = (uint64_t)cc;
-    while (seen_slots / 2 < cand_cap * (2 * kmax + 1))
+    // dedupe set: one key per reported hit, so twice the hit capacity is room enough
+    uint64_t seen_slots = 1u << 16;
+    while (seen_slots < 2 * std::min<uint64_t>(cand_cap * (2 * kmax + 1), std::max<uint64_t>(H->cap, 1)))
         seen_slots <<= 1;
     const size_t cand_bytes = cand_cap * sizeof(candidate);
     const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
@@ -1407,7 +1418,21 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         unsigned long long c[4] = {0, 0, 0, 0};
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (c[1] > H->cand_cap && c[2] == 0 && c[1] <= (1ull << 25) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
+            // more candidates than the buffer was sized for (short keys on a long text): the first attempt counted
+            // them, the second has room
+            A.cand_cap_override = c[1] + c[1] / 8 + 4096;
+            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            rc = run_filter(A);
+            if (rc != SPM_OK)
+                return rc;
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+            SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            H->stats.main_launches = (uint32_t)patterns->fidx.size();
+        }
         H->stats.n_candidates = c[1];
+        if (c[1] <= H->cand_cap)
+            patterns->cand_hint = std::max<uint64_t>(patterns->cand_hint, c[1]);
         if (c[1] > H->cand_cap || c[2] != 0) {
             H->stats.fell_back = 1;
             use_filter = false;

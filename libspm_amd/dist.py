@@ -24,8 +24,9 @@ def shard_range(n_total: int, rank: int, world: int, align: int = 1024):
 
 
 def gatherv_hits(local: torch.Tensor, dst: int = 0, group=None):
-    """local: int64 tensor [n, 2] (16-byte hit records viewed as two int64).  Returns on `dst` the concatenation
-    of every rank's records in rank order (= ascending shard order), elsewhere None."""
+    """local: int64 tensor [n, w] (hit records viewed as int64 words: w = 2 for the 16-byte spm_hit, 3 for the 24-byte
+    spm_jst_hit).  Returns on `dst` the concatenation of every rank's records in rank order (= ascending shard
+    order), elsewhere None."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -40,7 +41,7 @@ def gatherv_hits(local: torch.Tensor, dst: int = 0, group=None):
     counts = [int(c.item()) for c in counts]
     local = local.contiguous()
     if rank == dst:
-        out = torch.empty((sum(counts), 2), dtype=torch.int64, device=local.device)
+        out = torch.empty((sum(counts), local.shape[1]), dtype=torch.int64, device=local.device)
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + c)

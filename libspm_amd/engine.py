@@ -297,25 +297,59 @@ class Jst:
         _check(capi.lib().spm_hip_jst_stats(self._h, C.byref(st)), self.ctx._h)
         return st
 
-    def search(self, pats: PatternSet, *, engine: int = capi.ENGINE_AUTO, max_hits: int = 0) -> np.ndarray:
-        """All hits over all haplotypes, sorted by (haplotype, pos, pattern): JST_HIT_DTYPE records."""
+    def search_device(self, pats: PatternSet, *, engine: int = capi.ENGINE_AUTO, max_hits: int = 0) -> "JstHits":
+        """One search over all haplotypes; the records stay in HBM (arrival order) until view()/copy_to()."""
         opts = capi.ScanOpts(engine=engine, left_context=0, pos_offset=0, max_hits=max_hits, flags=0, reserved=0)
         hh = C.c_void_p()
         _check(capi.lib().spm_hip_jst_search(self._h, pats._h, C.byref(opts), C.byref(hh)), self.ctx._h)
+        return JstHits(self.ctx, hh)
+
+    def search(self, pats: PatternSet, *, engine: int = capi.ENGINE_AUTO, max_hits: int = 0) -> np.ndarray:
+        """All hits over all haplotypes, sorted by (haplotype, pos, pattern): JST_HIT_DTYPE records."""
+        h = self.search_device(pats, engine=engine, max_hits=max_hits)
         try:
-            rec = C.POINTER(capi.JstHit)()
-            n = C.c_uint64(0)
-            _check(capi.lib().spm_hip_jst_hits_view(hh, C.byref(rec), C.byref(n)), self.ctx._h)
-            if n.value == 0:
-                return np.zeros(0, dtype=JST_HIT_DTYPE)
-            buf = (capi.JstHit * n.value).from_address(C.addressof(rec.contents))
-            return np.frombuffer(buf, dtype=JST_HIT_DTYPE).copy()
+            return h.view()
         finally:
-            capi.lib().spm_hip_jst_hits_destroy(hh)
+            h.close()
 
     def close(self):
         if self._h:
             capi.lib().spm_hip_jst_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class JstHits:
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    def __len__(self):
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(capi.lib().spm_hip_jst_hits_device(self._h, C.byref(p), C.byref(n)), self.ctx._h)
+        return int(n.value)
+
+    def view(self) -> np.ndarray:
+        rec = C.POINTER(capi.JstHit)()
+        n = C.c_uint64(0)
+        _check(capi.lib().spm_hip_jst_hits_view(self._h, C.byref(rec), C.byref(n)), self.ctx._h)
+        if n.value == 0:
+            return np.zeros(0, dtype=JST_HIT_DTYPE)
+        buf = (capi.JstHit * n.value).from_address(C.addressof(rec.contents))
+        return np.frombuffer(buf, dtype=JST_HIT_DTYPE).copy()
+
+    def copy_to(self, device_ptr: int, cap: int) -> int:
+        n = C.c_uint64(0)
+        _check(capi.lib().spm_hip_jst_hits_copy_device(self._h, device_ptr, cap, C.byref(n)), self.ctx._h)
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            capi.lib().spm_hip_jst_hits_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -29,11 +29,15 @@ def _worker(rank, world, port, counts, q):
         buf[0, 0] = n
         buf[1:1 + n] = local
         fused = sdist.split_fused(sdist.gather_hits_fused(buf))
+        # 24-byte journaled-sequence hit records (three int64 words) go through the same gatherv
+        wide = torch.cat([local, (local[:, :1] * 3 + 1)], dim=1)
+        out3 = sdist.gatherv_hits(wide, dst=0)
         if rank == 0:
             assert torch.equal(fused, out)
+            assert out3.shape[1] == 3 and torch.equal(out3[:, :2], out) and torch.equal(out3[:, 2], out[:, 0] * 3 + 1)
             q.put(out.numpy().copy())
         else:
-            assert out is None
+            assert out is None and out3 is None
     finally:
         dist.destroy_process_group()
 
