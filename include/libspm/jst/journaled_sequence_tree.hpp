@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string_view>
 #include <unordered_map>
 
@@ -52,6 +53,21 @@ class journaled_sequence_tree
 {
     std::vector<std::uint8_t> _reference;
     io::vcf_data _variants;
+
+    // the tree resident on the MI355X (reference text + allele table + context index), built on first use
+    struct device_tree
+    {
+        hip::text_ptr reference{};
+        spm_jst * tree{};
+        bool tried{}, usable{};
+        std::size_t window{}, block{};
+        ~device_tree()
+        {
+            if (tree)
+                spm_hip_jst_destroy(tree);
+        }
+    };
+    std::shared_ptr<device_tree> _device{std::make_shared<device_tree>()};
 
 public:
     journaled_sequence_tree(std::vector<std::uint8_t> reference, io::vcf_data variants) :
@@ -261,8 +277,101 @@ public:
 
     // Search a compiled needle set over every haplotype.  `window` = max spm::window_size of the set, `needle_len`
     // = per-needle lengths (exact matchers report the begin position, so the last symbol is begin + |P| - 1).
+    // The contexts are cut, deduplicated and spelled out on the device (spm_hip_jst_*, include/spm_hip.h); trees the
+    // device path does not take (alleles overlapping on a shared haplotype, > 1024 haplotypes) go through
+    // search_host, which builds the same contexts on the host.  Both return the same hits.
     std::vector<jst_hit> search(spm_patterns * needles, std::size_t window, std::vector<std::uint32_t> const & needle_len,
                                 bool reports_begin, std::size_t block = 0, jst_search_stats * stats = nullptr) const
+    {
+        if (device_ready())
+            return search_device(needles, window, block, stats);
+        return search_host(needles, window, needle_len, reports_begin, block, stats);
+    }
+
+    // true once the tree is resident on the device (first call uploads it)
+    bool device_ready() const
+    {
+        device_tree & D = *_device;
+        if (D.tried)
+            return D.usable;
+        D.tried = true;
+        spm_ctx * ctx = hip::default_context();
+        std::size_t const H = haplotype_count(), cw = (H + 63) / 64;
+        std::vector<spm_jst_allele> al;
+        std::vector<std::uint8_t> pool;
+        std::vector<std::uint64_t> cov;
+        al.reserve(_variants.alleles.size());
+        cov.reserve(_variants.alleles.size() * cw);
+        for (io::vcf_allele const & a : _variants.alleles) {
+            al.push_back({a.pos, static_cast<std::uint32_t>(a.ref_len), static_cast<std::uint32_t>(a.alt.size()), pool.size()});
+            pool.insert(pool.end(), a.alt.begin(), a.alt.end());
+            for (std::size_t w = 0; w < cw; ++w) {
+                std::uint64_t bits = 0;
+                for (std::size_t h = w * 64; h < std::min(H, (w + 1) * 64); ++h)
+                    bits |= static_cast<std::uint64_t>(a.coverage[h] != 0) << (h & 63);
+                cov.push_back(bits);
+            }
+        }
+        std::uint32_t sigma = 4;
+        for (std::uint8_t c : _reference)
+            sigma = std::max<std::uint32_t>(sigma, c + 1u);
+        for (std::uint8_t c : pool)
+            sigma = std::max<std::uint32_t>(sigma, c + 1u);
+        spm_text * t = nullptr;
+        if (H == 0 || spm_hip_text_upload(ctx, _reference.data(), _reference.size(), sigma, &t) != SPM_OK)
+            return false;
+        D.reference = hip::text_ptr{t};
+        int const rc = spm_hip_jst_create(ctx, t, al.data(), al.size(), pool.data(), pool.size(), cov.data(),
+                                          static_cast<std::uint32_t>(H), &D.tree);
+        if (rc == SPM_E_HIP)
+            hip::fatal("spm_hip_jst_create", ctx);
+        D.usable = rc == SPM_OK;
+        return D.usable;
+    }
+
+    std::vector<jst_hit> search_device(spm_patterns * needles, std::size_t window, std::size_t block = 0,
+                                       jst_search_stats * stats = nullptr) const
+    {
+        spm_ctx * ctx = hip::default_context();
+        if (!device_ready())
+            hip::fatal("journaled_sequence_tree::search_device (tree not representable on the device)", ctx);
+        device_tree & D = *_device;
+        window = std::max<std::size_t>(window, 1);
+        if (D.window != window || D.block != block) { // index once per (window, block)
+            if (spm_hip_jst_index(D.tree, static_cast<std::uint32_t>(window), static_cast<std::uint32_t>(block), 0, 0) != SPM_OK)
+                hip::fatal("spm_hip_jst_index", ctx);
+            D.window = window;
+            D.block = block;
+        }
+        spm_jst_stats st{};
+        spm_hip_jst_stats(D.tree, &st);
+        spm_scan_opts opts{};
+        opts.max_hits = std::max<std::uint64_t>(1u << 22, 8 * st.context_symbols / window);
+        spm_jst_hits * hh = nullptr;
+        if (spm_hip_jst_search(D.tree, needles, &opts, &hh) != SPM_OK)
+            hip::fatal("spm_hip_jst_search", ctx);
+        spm_jst_hit const * rec = nullptr;
+        std::uint64_t n = 0;
+        if (spm_hip_jst_hits_view(hh, &rec, &n) != SPM_OK)
+            hip::fatal("spm_hip_jst_hits_view", ctx);
+        std::vector<jst_hit> out;
+        out.reserve(n);
+        for (std::uint64_t i = 0; i < n; ++i)
+            out.push_back({rec[i].haplotype, rec[i].pos, rec[i].pattern, rec[i].score});
+        spm_hip_jst_hits_destroy(hh);
+        if (stats) {
+            stats->haplotype_symbols = st.haplotype_symbols;
+            stats->context_symbols = st.context_symbols;
+            stats->contexts = st.contexts;
+            stats->unique_contexts = st.unique_contexts;
+        }
+        std::sort(out.begin(), out.end());
+        return out;
+    }
+
+    // The same search with the contexts built on the host (any allele table) and uploaded.
+    std::vector<jst_hit> search_host(spm_patterns * needles, std::size_t window, std::vector<std::uint32_t> const & needle_len,
+                                     bool reports_begin, std::size_t block = 0, jst_search_stats * stats = nullptr) const
     {
         spm_ctx * ctx = hip::default_context();
         std::size_t const L = block ? block : std::max<std::size_t>(256, 4 * window);

@@ -179,6 +179,11 @@ static void fixture_cases(char const * vcf, char const * haplotypes)
                     (unsigned long long)st.unique_contexts, (unsigned long long)st.contexts);
         EXPECT_TRUE(got.size() >= 48);
         EXPECT_TRUE(got == want);
+        EXPECT_TRUE(jst.device_ready()); // contexts were cut and deduplicated on the device ...
+        spm::jst_search_stats st_host{};
+        auto got_host = jst.search_host(ns.compiled.get(), ns.window, ns.lens, c.begin, 0, &st_host);
+        EXPECT_TRUE(got_host == want);   // ... and the host-built contexts give the same hits
+        EXPECT_TRUE(st_host.haplotype_symbols == st.haplotype_symbols);
         // a different block length must not change anything
         auto got2 = jst.search(ns.compiled.get(), ns.window, ns.lens, c.begin, 777, nullptr);
         EXPECT_TRUE(got2 == want);
@@ -260,8 +265,8 @@ static void synthetic_case()
     EXPECT_TRUE(got.size() >= 64);
     EXPECT_TRUE(st.context_symbols * 4 < st.haplotype_symbols);
 
-    // C5-shaped needles: |P| = 1024, k <= 64 (q = 15 < 16: no seed filter, the cut-off brute kernel scans the
-    // contexts as segmented haystacks).  Needles carry up to 64 planted substitutions.
+    // C5-shaped needles: |P| = 1024, k <= 64 (seeds of q = 15 symbols, 14-symbol keys; contexts scanned as segmented
+    // haystacks).  Needles carry up to 64 planted substitutions.
     needle_set big = make_needles(jst, SPM_ALGO_MYERS, 1024, 64, 8);
     auto got_big = jst.search(big.compiled.get(), big.window, big.lens, false, 0, &st);
     auto want_big = linear_scans(jst, big);
@@ -270,6 +275,7 @@ static void synthetic_case()
                 double(st.haplotype_symbols) / double(st.context_symbols));
     EXPECT_TRUE(got_big == want_big);
     EXPECT_TRUE(got_big.size() >= 8);
+    EXPECT_TRUE(jst.search_host(big.compiled.get(), big.window, big.lens, false, 0, nullptr) == want_big);
 }
 
 int main(int argc, char ** argv)
