@@ -93,7 +93,7 @@ typedef struct spm_scan_stats {
     uint64_t n_candidates;
     uint64_t n_hits;
     uint32_t main_launches;
-    uint32_t reserved;
+    uint32_t n_bands;     /* filter engine, needles with k >= 8: diagonal bands verified after candidate merging */
 } spm_scan_stats;
 
 /* ---- context -------------------------------------------------------------------------------------- */

@@ -47,7 +47,7 @@ class ScanStats(C.Structure):
         ("n_candidates", C.c_uint64),
         ("n_hits", C.c_uint64),
         ("main_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("n_bands", C.c_uint32),
     ]
 
 

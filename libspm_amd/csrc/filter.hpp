@@ -41,10 +41,20 @@ constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
 
 struct candidate
 {
-    uint64_t t;   // text index of the window start
-    uint32_t val; // pattern << 11 | offset of the window inside the pattern
-    uint32_t pad;
+    uint64_t t;   // text index of the window start            | merged: first diagonal of the band (int64)
+    uint32_t val; // pattern << 11 | offset of the window inside the pattern   | merged: pattern << 11 | band width - 1
+    uint32_t pad; // 0                                          | merged: segment index + 1
 };
+
+// Candidate slots are handed to the waves in chunks of 16: one atomic on the shared counter per chunk instead of one
+// per survivor (a single address takes ~100 atomics/us; 14-symbol keys on a 1.5 GiB text produce 10^5 survivors, which
+// cost 0.8 of the kernel's 1.2 ms before).  Slots a wave reserved but did not fill are marked invalid.
+constexpr uint32_t kCandChunk = 16;
+constexpr uint32_t kCandInvalid = 0xFFFFFFFFu; // candidate.val of an unused slot (pattern index 2^21 - 1 never exists)
+// The chunk a wave is filling lives in LDS behind the level-1 table ({base lo, base hi, used, size} per wave; touched
+// only on the rare survivor path, so nothing stays live across the streaming loop): slots [base + used, base + size)
+// are free.  size = 16, or the number of survivors of one ballot if that is larger.
+constexpr uint32_t kCandLdsSlot = 4; // words after lds_words where the per-wave chunk records start
 
 struct filter_params
 {
@@ -179,6 +189,36 @@ __device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
                           __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
     }
     return *reinterpret_cast<const uint4 *>(p);
+}
+
+// one atomic per wave: add the lanes' counts to a statistics counter (call with the wave converged)
+__device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v)
+        atomicAdd(counter, (unsigned long long)v);
+}
+
+// this wave's chunk record in LDS
+__device__ __forceinline__ uint32_t *cand_chunk_of(const filter_params &P, const uint32_t *lds)
+{
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    return const_cast<uint32_t *>(lds) + P.lds_words + kCandLdsSlot + 4 * wave;
+}
+
+// mark the unused tail of a wave's chunk invalid (wave-uniform call)
+__device__ __forceinline__ void cand_close(const filter_params &P, const uint32_t *ck, uint32_t lane)
+{
+    const uint32_t used = ck[2], size = ck[3];
+    const uint64_t idx = (((uint64_t)ck[1] << 32) | ck[0]) + used + lane;
+    if (used + lane < size && idx < P.cand_cap) {
+        candidate c;
+        c.t = 0;
+        c.val = kCandInvalid;
+        c.pad = 0;
+        P.cand[idx] = c;
+    }
 }
 
 // Level 1 + level 2 on NWD 2-bit-packed words per lane (w[j] = 16 bases, prev[j] = the 16 bases before them).
@@ -327,19 +367,55 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
             const uint64_t m = __ballot(emit);
             if (m != 0) {
                 const uint32_t n = __popcll(m);
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                unsigned long long base = 0;
-                if ((int)lane == leader)
-                    base = atomicAdd(&P.counters[1], (unsigned long long)n);
-                base = __shfl(base, leader);
-                if (emit) {
-                    const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
-                    if (idx < P.cand_cap) {
-                        candidate c;
-                        c.t = t;
-                        c.val = val;
-                        c.pad = 0;
-                        P.cand[idx] = c;
+                if constexpr (S <= 2) {
+                    // strides 1 and 2 (huge needle sets, short keys) see 10^5..10^6 survivors: slots come in chunks
+                    uint32_t *ck = cand_chunk_of(P, lds);
+                    uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
+                    if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
+                        cand_close(P, ck, lane);
+                        const uint32_t size = n > kCandChunk ? n : kCandChunk;
+                        if (lane == 0) {
+                            const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
+                            ck[0] = (uint32_t)b;
+                            ck[1] = (uint32_t)(b >> 32);
+                            ck[3] = size;
+                        }
+                        used = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint64_t cbase = ((uint64_t)ck[1] << 32) | ck[0];
+                    if (emit) {
+                        const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
+                        if (idx < P.cand_cap) {
+                            candidate c;
+                            c.t = t;
+                            c.val = val;
+                            c.pad = 0;
+                            P.cand[idx] = c;
+                        }
+                    }
+                    if (lane == 0)
+                        ck[2] = used + n;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // the larger strides see a few thousand survivors per scan: one atomic per ballot is cheaper
+                    // than carrying the chunk bookkeeping through the streaming kernel (measured: C3 2.49 vs 2.60 ms)
+                    const int leader = __ffsll((unsigned long long)m) - 1;
+                    unsigned long long base = 0;
+                    if ((int)lane == leader)
+                        base = atomicAdd(&P.counters[1], (unsigned long long)n);
+                    base = __shfl(base, leader);
+                    if (emit) {
+                        const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
+                        if (idx < P.cand_cap) {
+                            candidate c;
+                            c.t = t;
+                            c.val = val;
+                            c.pad = 0;
+                            P.cand[idx] = c;
+                        }
                     }
                 }
             }
@@ -387,6 +463,13 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
     // ---- stage the Bloom bitmap in LDS (once per workgroup; the grid is persistent) ----
     for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
         lds[i] = P.bitmap[i];
+    if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
+        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + 4 * (threadIdx.x >> 6);
+        ck[0] = 0;
+        ck[1] = 0;
+        ck[2] = 0;
+        ck[3] = 0; // size 0: the first survivor draws a chunk
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
@@ -471,6 +554,11 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     nxt[u] = load16_stream<NT>(lane_text + pf * 1024 + (uint64_t)u * ustride);
+                // strides 1 and 2: keep the loads here -- left alone, the scheduler sinks them to the very end of the
+                // group's work and the next iteration waits out the whole HBM latency.  (The larger strides are
+                // scheduled well as they are; a barrier there only forces the packing to wait for all eight loads.)
+                if constexpr (S <= 2)
+                    __builtin_amdgcn_sched_barrier(0);
                 filter_group<S, U, HV, SIG, KM>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
             }
         }
@@ -482,6 +570,8 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
         }
         sp += n_waves;
     }
+    if constexpr (S <= 2)
+        cand_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -513,6 +603,13 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
     extern __shared__ uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
         lds[i] = P.bitmap[i];
+    if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
+        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + 4 * (threadIdx.x >> 6);
+        ck[0] = 0;
+        ck[1] = 0;
+        ck[2] = 0;
+        ck[3] = 0; // size 0: the first survivor draws a chunk
+    }
     __syncthreads();
 
     constexpr int NWD = 4 * U2;
@@ -581,6 +678,7 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
 #pragma unroll
             for (int u = 0; u < U2; ++u)
                 nxt[u] = load16_stream<true>(reinterpret_cast<const uint8_t *>(lane_src + pf * 64 + (uint64_t)u * ustride));
+            __builtin_amdgcn_sched_barrier(0); // as in seed_filter_kernel: the prefetch stays ahead of the group's work
             uint32_t w[NWD], prev[NWD];
             const uint32_t nv[1] = {0};
 #pragma unroll
@@ -602,6 +700,8 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
         }
         sp += n_waves;
     }
+    if constexpr (S <= 2)
+        cand_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -626,7 +726,9 @@ struct verify_params
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
-    uint32_t pad;
+    uint32_t max_span;     // merged candidates: extra end positions a diagonal band answers for (0: none merged)
+    uint32_t cand_counter; // index of the candidate count in `counters` (1: raw candidates, 3: merged bands)
+    uint32_t wave_text;    // wave-per-candidate kernel: bytes of LDS per group for the candidate's text window
     unsigned long long *seen; // hash set of (pattern << 40 | end)
     uint32_t seen_mask;
     spm_hit *hits;
@@ -645,41 +747,52 @@ struct verify_params
 template <int NWN>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
-    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x] words, then [2*max_k + 1][blockDim.x] uint16
+    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x] words, then [2*max_k + 1 + max_span][blockDim.x] uint16
     const uint32_t tid = threadIdx.x;
     const uint32_t nthr = blockDim.x;
     const uint32_t rows = P.sigma + 1;
     uint16_t *hitbuf = reinterpret_cast<uint16_t *>(vlds + (size_t)rows * NWN * nthr);
-    for (uint32_t r = 0; r <= 2 * P.max_k; ++r)
+    const uint32_t n_slots = 2 * P.max_k + 1 + P.max_span;
+    for (uint32_t r = 0; r < n_slots; ++r)
         hitbuf[(size_t)r * nthr + tid] = 0;
-    unsigned long long n_cand = P.counters[1];
+    unsigned long long n_cand = P.counters[P.cand_counter];
     if (n_cand > P.cand_cap)
         n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
     const uint64_t stride = (uint64_t)gridDim.x * nthr;
+    uint32_t n_valid = 0;
     for (uint64_t ci = (uint64_t)blockIdx.x * nthr + tid; ci < n_cand; ci += stride) {
         const candidate c = P.cand[ci];
+        if (c.val == kCandInvalid)
+            continue; // a slot its wave reserved but did not fill
+        ++n_valid;
         const uint32_t pat = c.val >> 11;
-        const int64_t x = c.val & 0x7FF;
+        const bool merged = c.pad != 0;
+        const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF);
+        const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : 0;
         const int64_t m = P.m[pat];
         const int64_t k = P.k[pat];
         const int64_t d = (int64_t)c.t - x; // diagonal: needle position 0 <-> text index d
-        // exclusive end positions this candidate answers for: e in [d+m-k, d+m+k]
+        // exclusive end positions this candidate answers for: e in [d+m-k, d+m+k] (a band: up to diagonal d+span)
         int64_t e_lo = d + m - k;
-        int64_t e_hi = d + m + k;
+        int64_t e_hi = d + m + k + span;
         // ownership: last symbol e-1 in [scan_begin, scan_end)
         int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
         if (P.seg_offsets) {
             // every segment is a haystack of its own: find the one holding the key window, clamp to it
             uint64_t lo = 0, hi = P.n_segments; // invariant: seg_offsets[lo] <= t < seg_offsets[hi]
-            while (hi - lo > 1) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (P.seg_offsets[mid] <= c.t)
-                    lo = mid;
-                else
-                    hi = mid;
+            if (merged) {
+                lo = c.pad - 1;
+            } else {
+                while (hi - lo > 1) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (P.seg_offsets[mid] <= c.t)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
             }
             const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
-            if ((int64_t)c.t + (int64_t)P.key_len > se)
+            if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
                 continue; // the key window straddles two haystacks
             own_b = sb;
             own_e = se;
@@ -740,7 +853,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         }
         // ---- deferred emission: slot r = end position e_lo + r ----
         if (__ballot(any_hit) != 0) {
-            for (int64_t r = 0; r <= 2 * (int64_t)P.max_k; ++r) {
+            for (int64_t r = 0; r < (int64_t)n_slots; ++r) {
                 uint32_t sc1 = 0;
                 if (any_hit && r <= e_hi - e_lo) {
                     sc1 = hitbuf[(size_t)r * nthr + tid];
@@ -773,6 +886,323 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
                     wave_append_hits(fresh, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
                                      (int32_t)sc1 - 1, P.hits, P.hit_counter, P.hit_cap);
             }
+        }
+    }
+    if (P.cand_counter == 1) // raw candidates: how many reserved slots were real ones
+        wave_count_add(P.hit_counter + 5, n_valid);
+}
+
+
+// ---- wave-per-candidate verification for long needles ----------------------------------------------------------
+// One lane per 32-row block of the needle instead of one lane per candidate: G lanes form a systolic array that runs
+// the block-based Myers recurrence (Myers 1999 / Hyyro 2003: every block takes the horizontal delta hin of the block
+// above and hands its own hout down).  At step t lane b processes text column t - b; the text symbol and hout travel
+// one lane per step through DPP wave_shr:1.  A column of a 1024-row needle costs one step of ~40 instructions
+// instead of 32 blocks x 13 on a single lane, so the latency of one verification drops from ~1.5 ms to ~0.1 ms --
+// what matters when a scan leaves a few hundred long bands to verify.  Reads the bottom-aligned table of the cut-off
+// kernel ([group][row][nw_table][64]); each lane keeps the <= 5 match masks of its block in registers.
+template <int G>
+__global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P, const uint32_t *__restrict__ peq_bot)
+{
+    // per group of G lanes: [2*max_k + 1 + max_span] uint16 hit slots, then the candidate's text window (wave_text bytes)
+    extern __shared__ uint16_t whit[];
+    constexpr uint32_t GPW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63, gl = lane & (G - 1), gw = lane / G;
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t n_slots = 2 * P.max_k + 1 + P.max_span;
+    const uint32_t group_bytes = ((n_slots * 2 + 15) & ~15u) + P.wave_text;
+    uint8_t *gbase = reinterpret_cast<uint8_t *>(whit) + (size_t)(wave * GPW + gw) * group_bytes;
+    uint16_t *hb = reinterpret_cast<uint16_t *>(gbase);
+    uint8_t *tw = gbase + ((n_slots * 2 + 15) & ~15u);
+    for (uint32_t r = gl; r < n_slots; r += G)
+        hb[r] = 0;
+    unsigned long long n_cand = P.counters[P.cand_counter];
+    if (n_cand > P.cand_cap)
+        n_cand = P.cand_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * waves * GPW;
+    const uint32_t rows = P.sigma + 1;
+    uint32_t n_valid = 0;
+    for (uint64_t base = ((uint64_t)blockIdx.x * waves + wave) * GPW; base < n_cand; base += stride) {
+        const uint64_t ci = base + gw;
+        bool active = ci < n_cand;
+        uint32_t pat = 0;
+        int64_t m = 1, k = 0, e_lo = 0, e_hi = -1, ws = 0;
+        candidate c;
+        c.val = kCandInvalid;
+        if (active)
+            c = P.cand[ci];
+        active = active && c.val != kCandInvalid;
+        if (active && gl == 0)
+            ++n_valid;
+        if (active) {
+            pat = c.val >> 11;
+            const bool merged = c.pad != 0;
+            const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF);
+            const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : 0;
+            m = P.m[pat];
+            k = P.k[pat];
+            const int64_t d = (int64_t)c.t - x;
+            e_lo = d + m - k;
+            e_hi = d + m + k + span;
+            int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
+            if (P.seg_offsets) {
+                uint64_t lo = 0, hi = P.n_segments;
+                if (merged) {
+                    lo = c.pad - 1;
+                } else {
+                    while (hi - lo > 1) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (P.seg_offsets[mid] <= c.t)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                }
+                const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
+                if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
+                    active = false;
+                own_b = sb;
+                own_e = se;
+                hay_b = sb;
+            }
+            if (e_lo < own_b + 1)
+                e_lo = own_b + 1;
+            if (e_hi > own_e)
+                e_hi = own_e;
+            if (e_lo > e_hi)
+                active = false;
+            ws = e_lo - (m + k);
+            if (ws < hay_b)
+                ws = hay_b;
+        }
+        const uint32_t nb = (uint32_t)((m + 31) >> 5);        // blocks of this needle
+        const bool is_last = gl + 1 == nb;
+        const uint32_t out_bit = is_last ? (uint32_t)((m - 1) & 31) : 31u; // where this block's hout is read
+        const uint32_t n_cols = active ? (uint32_t)(e_hi - ws) : 0u;
+        const bool mine = active && gl < nb;
+        // ---- stage the text window [ws, e_hi) into LDS: 16-byte blocks, the group's lanes side by side ----
+        const uint32_t skew = (uint32_t)(ws & 15);
+        if (active) {
+            const uint32_t n_bytes = (skew + n_cols + 15) & ~15u;
+            for (uint32_t off = gl * 16; off < n_bytes; off += G * 16) {
+                const uint4 v = load_text16(P.text, ((uint64_t)ws & ~15ull) + off, P.text_alloc);
+                *reinterpret_cast<uint4 *>(tw + off) = v;
+            }
+        }
+        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+        if (mine) {
+            const uint32_t *src = peq_bot + (((size_t)(pat >> 6) * rows) * P.nw_table + gl) * 64 + (pat & 63);
+            const size_t rs = (size_t)P.nw_table * 64;
+            e0 = src[0];
+            e1 = src[rs];
+            e2 = P.sigma > 2 ? src[2 * rs] : 0u;
+            e3 = P.sigma > 3 ? src[3 * rs] : 0u;
+            e4 = P.sigma > 4 ? src[4 * rs] : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t Pv = 0xFFFFFFFFu, Mv = 0, ho = 0;
+        int32_t score = (int32_t)m;
+        bool any_hit = false;
+        const uint32_t first_slot_col = (uint32_t)(e_lo - ws) - 1; // column whose end position is e_lo
+        const uint32_t t_end = n_cols + nb - 1;                    // steps until the last block has seen the last column
+        // wave-uniform trip count: the longest group decides
+        uint32_t t_wave = active ? t_end : 0u;
+        for (int o = 32; o >= (int)G; o >>= 1)
+            t_wave = max(t_wave, (uint32_t)__shfl_xor((int)t_wave, o));
+        t_wave = (uint32_t)__builtin_amdgcn_readfirstlane(t_wave);
+        const uint8_t *my_text = tw + skew - gl; // column t - gl of this lane = my_text[t]
+        uint32_t sym_next = mine ? my_text[gl] : 0u; // column 0 (clamped reads below keep every index inside the window)
+        for (uint32_t t = 0; t < t_wave; ++t) {
+            const uint32_t ho_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ho, 0x138, 0xF, 0xF, false);
+            const uint32_t col = t - gl; // wraps for t < gl: then col >= n_cols
+            const uint32_t sym = sym_next;
+            {   // next column's symbol, one step ahead of its use
+                uint32_t nc = col + 1;
+                nc = nc < n_cols ? nc : 0u;
+                sym_next = tw[skew + nc];
+            }
+            if (mine && col < n_cols) {
+                const uint32_t lo2 = (sym & 1u) ? e1 : e0, hi2 = (sym & 1u) ? e3 : e2;
+                uint32_t Eq = (sym & 2u) ? hi2 : lo2;
+                if (P.sigma != 4)
+                    Eq = sym < 4 ? Eq : (sym == 4 ? e4 : 0u);
+                Eq = sym < P.sigma ? Eq : 0u;
+                const uint32_t hin = gl == 0 ? 0u : ho_up;
+                const uint32_t hp = hin & 1u, hn = hin >> 1;
+                const uint32_t Xv = Eq | Mv;
+                Eq |= hn;
+                const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                uint32_t Ph = Mv | ~(Xh | Pv);
+                uint32_t Mh = Pv & Xh;
+                const uint32_t op = (Ph >> out_bit) & 1u, on = (Mh >> out_bit) & 1u;
+                ho = op | (on << 1);
+                Ph = (Ph << 1) | hp;
+                Mh = (Mh << 1) | hn;
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                score += (int32_t)op - (int32_t)on;
+                if (is_last && score <= (int32_t)k && col >= first_slot_col) {
+                    hb[col - first_slot_col] = (uint16_t)(score + 1);
+                    any_hit = true;
+                }
+            }
+        }
+        (void)my_text;
+        // ---- emission: the lanes of a group share its slots; wave-converged appends ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(any_hit) != 0) {
+            for (uint32_t r0 = 0; r0 < n_slots; r0 += G) {
+                const uint32_t r = r0 + gl;
+                uint32_t sc1 = 0;
+                if (active && r < n_slots && (int64_t)r <= e_hi - e_lo) {
+                    sc1 = hb[r];
+                    hb[r] = 0;
+                }
+                bool is_new = false;
+                const int64_t e = e_lo + r;
+                if (sc1) {
+                    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
+                    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
+                    bool placed = false;
+                    for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
+                        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
+                        if (old == ~0ull) {
+                            is_new = true;
+                            placed = true;
+                        } else if (old == key) {
+                            placed = true;
+                        } else {
+                            slot = (slot + 1) & P.seen_mask;
+                        }
+                    }
+                    if (!placed)
+                        atomicAdd(P.overflow, 1ull);
+                }
+                if (__ballot(is_new) != 0)
+                    wave_append_hits(is_new, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
+                                     (int32_t)sc1 - 1, P.hits, P.hit_counter, P.hit_cap);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (P.cand_counter == 1)
+        wave_count_add(P.hit_counter + 5, n_valid);
+}
+
+// ---- candidate merging for large k ------------------------------------------------------------------------------
+// With k+1 seeds every occurrence is verified once per surviving seed (65 times for k = 64) and short keys let chance
+// matches through.  Needles with k >= kMergeMinK therefore carry k+2 seeds: an occurrence with <= k errors keeps >= 2 of
+// them intact, on diagonals at most k apart.  Candidates are counted per (needle, haystack, diagonal band); a band is
+// verified once, over every end position its diagonals can produce, if it collected as many seed hits as the needle
+// has surplus seeds (1 for needles that kept k+1 seeds).  Bands are Bw diagonals wide and overlap by k, so the intact
+// seeds of one occurrence always share a band.
+struct merge_params
+{
+    const candidate *cand;
+    const unsigned long long *counters; // [1] raw candidates
+    unsigned long long *out_count;      // counters[3]
+    uint64_t cand_cap;
+    const int32_t *m, *k;
+    const uint8_t *surplus; // per needle: seeds - k
+    uint32_t key_len, max_m, Bw, table_mask;
+    uint64_t hay_begin; // unsegmented scans: first symbol of the haystack
+    const uint64_t *seg_offsets;
+    uint64_t n_segments;
+    uint2 *aux;      // per candidate: {segment, primary band}; segment 0xFFFFFFFF = dropped
+    uint32_t *owner; // band table: (candidate << 1 | secondary) of the first arrival, 0xFFFFFFFF = empty
+    uint32_t *count; // seed hits per band
+    candidate *out;
+    uint64_t out_cap;
+};
+
+__global__ void merge_aux_kernel(const merge_params P)
+{
+    unsigned long long n = P.counters[1];
+    if (n > P.cand_cap)
+        n = P.cand_cap;
+    uint32_t n_valid = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const candidate c = P.cand[i];
+        n_valid += c.val != kCandInvalid ? 1u : 0u;
+        uint64_t seg = 0;
+        int64_t sb = (int64_t)P.hay_begin;
+        bool drop = c.val == kCandInvalid;
+        if (P.seg_offsets) {
+            uint64_t lo = 0, hi = P.n_segments;
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (P.seg_offsets[mid] <= c.t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            seg = lo;
+            sb = (int64_t)P.seg_offsets[lo];
+            drop = drop || (int64_t)c.t + (int64_t)P.key_len > (int64_t)P.seg_offsets[lo + 1];
+        }
+        // diagonal relative to the haystack, shifted so that it is never negative (t >= sb, offset <= max_m)
+        const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
+        P.aux[i] = drop ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2((uint32_t)seg, (uint32_t)(dr / (int64_t)P.Bw));
+    }
+    wave_count_add(P.out_count + 2, n_valid); // counters[5]
+}
+
+__global__ void merge_count_kernel(const merge_params P)
+{
+    unsigned long long n = P.counters[1];
+    if (n > P.cand_cap)
+        n = P.cand_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 a = P.aux[i];
+        if (a.x == 0xFFFFFFFFu)
+            continue;
+        const candidate c = P.cand[i];
+        const uint32_t pat = c.val >> 11;
+        const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
+        const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
+        // band b covers diagonals [b*Bw, (b+1)*Bw + k]: the primary band, and the one before it if this diagonal
+        // still lies in its k-wide extension
+        const bool also_prev = a.y > 0 && dr - (int64_t)a.y * P.Bw <= (int64_t)P.k[pat];
+        for (uint32_t sec = 0; sec <= (also_prev ? 1u : 0u); ++sec) {
+            const uint32_t band = a.y - sec;
+            uint32_t s = (uint32_t)mix64(((uint64_t)pat << 40) ^ ((uint64_t)a.x << 17) ^ band) & P.table_mask;
+            while (true) {
+                uint32_t o = atomicCAS(&P.owner[s], 0xFFFFFFFFu, (uint32_t)(i << 1) | sec);
+                if (o == 0xFFFFFFFFu)
+                    o = (uint32_t)(i << 1) | sec;
+                const uint2 b = P.aux[o >> 1];
+                if ((P.cand[o >> 1].val >> 11) == pat && b.x == a.x && b.y - (o & 1u) == band) {
+                    atomicAdd(&P.count[s], 1u);
+                    break;
+                }
+                s = (s + 1) & P.table_mask;
+            }
+        }
+    }
+}
+
+__global__ void merge_select_kernel(const merge_params P)
+{
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= P.table_mask; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o = P.owner[s];
+        if (o == 0xFFFFFFFFu)
+            continue;
+        const uint32_t pat = P.cand[o >> 1].val >> 11;
+        if (P.count[s] < P.surplus[pat])
+            continue;
+        const uint2 a = P.aux[o >> 1];
+        const uint32_t band = a.y - (o & 1u);
+        const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
+        const unsigned long long idx = atomicAdd(P.out_count, 1ull);
+        if (idx < P.out_cap) {
+            candidate c;
+            c.t = (uint64_t)(sb - (int64_t)P.max_m + (int64_t)band * P.Bw); // first diagonal of the band
+            c.val = (pat << 11) | (P.Bw + (uint32_t)P.k[pat]);                 // its last diagonal: + Bw + k
+            c.pad = a.x + 1;
+            P.out[idx] = c;
         }
     }
 }

@@ -72,6 +72,7 @@ struct spm_patterns
     int32_t *d_k = nullptr;
     std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
     mutable uint64_t cand_hint = 0; // most candidates a filter scan of this set has produced so far
+    uint8_t *d_surplus = nullptr;   // per needle: seeds - k (candidate merging); nullptr = no needle has k >= kMergeMinK
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
 };
@@ -93,6 +94,20 @@ static int env_int(const char *name, int dflt)
 static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
                            filter_index &F);
 
+// Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
+// needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
+// hits per diagonal band and skip bands with a single one (filter.hpp, candidate merging).
+constexpr uint32_t kMergeMinK = 8;
+struct seed_plan
+{
+    uint32_t n, q;
+};
+static inline seed_plan plan_seeds(uint32_t m, uint32_t k)
+{
+    const uint32_t surplus = (k >= kMergeMinK && k <= 1000 && m / (k + 2) >= kKeyMin) ? 2u : 1u;
+    return {k + surplus, m / (k + surplus)};
+}
+
 // Seed filter applicability + partition of the needle set into sub-batches whose keys fit one LDS table.
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
@@ -109,8 +124,9 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
         if (m == 0 || m > 2047)
             return SPM_OK;
-        qmin = std::min(qmin, m / (k + 1));
-        n_seeds += k + 1;
+        const seed_plan sp = plan_seeds(m, k);
+        qmin = std::min(qmin, sp.q);
+        n_seeds += sp.n;
     }
     if (qmin < kKeyMin)
         return SPM_OK;
@@ -153,7 +169,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         uint64_t keys = 0;
         uint32_t p1 = p0;
         while (p1 < ps->n) {
-            const uint64_t add = (uint64_t)((ps->is_myers() ? ps->k[p1] : 0) + 1) * S;
+            const uint64_t add = (uint64_t)plan_seeds((uint32_t)ps->m[p1], ps->is_myers() ? (uint32_t)ps->k[p1] : 0).n * S;
             if (keys + add > cap && p1 > p0)
                 break;
             keys += add;
@@ -197,9 +213,10 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     std::vector<kv> keys;
     for (uint32_t p = p_begin; p < p_end; ++p) {
         const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
-        const uint32_t q = m / (k + 1);
+        const seed_plan sp = plan_seeds(m, k);
+        const uint32_t q = sp.q;
         const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-        for (uint32_t j = 0; j <= k; ++j) {
+        for (uint32_t j = 0; j < sp.n; ++j) {
             const uint32_t o = j * q;
             for (uint32_t r = 0; r < S; ++r) {
                 // window seed[r, r+H) -- inside the seed because S <= q - H + 1
@@ -463,6 +480,13 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         int rc = build_filter_index(ctx, ps.get());
         if (rc != SPM_OK)
             return rc;
+        if (!ps->fidx.empty() && ps->max_k >= kMergeMinK && ps->max_k <= 1000) {
+            std::vector<uint8_t> surplus(ps->m.size(), 1);
+            for (uint32_t p = 0; p < ps->n; ++p)
+                surplus[p] = (uint8_t)(plan_seeds((uint32_t)ps->m[p], (uint32_t)ps->k[p]).n - (uint32_t)ps->k[p]);
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_surplus, surplus.size()));
+            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_surplus, surplus.data(), surplus.size(), hipMemcpyHostToDevice));
+        }
     }
     *out = ps.release();
     return SPM_OK;
@@ -478,6 +502,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_hp0);
     hipFree(p->d_m);
     hipFree(p->d_k);
+    hipFree(p->d_surplus);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
@@ -914,12 +939,39 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
     // LDS holds (sigma+1)*NWN words per thread; keep the block within ~128 KiB
     uint32_t threads = 256;
-    const size_t per_thread = (size_t)(V.sigma + 1) * NWN * 4 + 2 * (2 * (size_t)V.max_k + 1);
+    const size_t per_thread = (size_t)(V.sigma + 1) * NWN * 4 + 2 * (2 * (size_t)V.max_k + 1 + V.max_span);
     while (threads > 64 && per_thread * threads > 128 * 1024)
         threads >>= 1;
     const size_t lds = per_thread * threads;
     hipFuncSetAttribute((const void *)verify_kernel<NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_kernel<NWN>), grid, dim3(threads), lds, s, V);
+}
+
+template <int G>
+void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid, hipStream_t s)
+{
+    const uint32_t threads = 256;
+    const uint32_t n_slots = 2 * V.max_k + 1 + V.max_span;
+    // text window of one candidate: cold start |P| + k symbols before the first end position, then the end positions
+    V.wave_text = ((max_m + V.max_k + n_slots + 16 + 15) & ~15u) + 16;
+    const size_t per_group = ((n_slots * 2 + 15) & ~15u) + V.wave_text;
+    const size_t lds = (size_t)(threads / 64) * (64 / G) * per_group;
+    hipFuncSetAttribute((const void *)verify_wave_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((verify_wave_kernel<G>), grid, dim3(threads), lds, s, V, peq_bot);
+}
+
+// long needles: one lane per 32-row block, G = lanes per candidate >= blocks of the longest needle
+void launch_verify_wave(uint32_t n_blocks, const verify_params &V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid,
+                        hipStream_t s)
+{
+    if (n_blocks <= 8)
+        launch_verify_wave_g<8>(V, peq_bot, max_m, grid, s);
+    else if (n_blocks <= 16)
+        launch_verify_wave_g<16>(V, peq_bot, max_m, grid, s);
+    else if (n_blocks <= 32)
+        launch_verify_wave_g<32>(V, peq_bot, max_m, grid, s);
+    else
+        launch_verify_wave_g<64>(V, peq_bot, max_m, grid, s);
 }
 
 // nwn = 32-bit words that can hold needle rows = ceil(max |P| / 32), rounded up to an instantiated width
@@ -1085,6 +1137,7 @@ int run_filter(const scan_args &A)
         chance += (double)(A.end - A.begin) / std::max(1u, F.stride) * (double)F.n_keys / std::pow(4.0, (double)F.key_len);
     cand_cap = std::max<uint64_t>(cand_cap, (uint64_t)(2.0 * chance));
     cand_cap = std::max<uint64_t>(cand_cap, ps->cand_hint + ps->cand_hint / 4);
+    cand_cap += (uint64_t)ctx->n_cu * 16 * kCandChunk; // slots are drawn in chunks of 16 per wave: room for the tails
     cand_cap = std::min(cand_cap, kCandMax);
     if (A.cand_cap_override)
         cand_cap = A.cand_cap_override;
@@ -1097,12 +1150,28 @@ int run_filter(const scan_args &A)
         seen_slots <<= 1;
     const size_t cand_bytes = cand_cap * sizeof(candidate);
     const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
-    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes);
+    // candidate merging (needles with many errors): bands, per-candidate aux, band table
+    const bool merging = ps->d_surplus != nullptr && env_int("SPM_HIP_FILTER_MERGE", 1) != 0;
+    uint64_t band_slots = 1u << 12;
+    while (merging && band_slots < 4 * cand_cap)
+        band_slots <<= 1;
+    const size_t merged_bytes = merging ? 2 * cand_bytes : 0;
+    const size_t aux_bytes = merging ? cand_cap * sizeof(uint2) : 0;
+    const size_t table_bytes = merging ? band_slots * 2 * sizeof(uint32_t) : 0;
+    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes);
     if (rc != SPM_OK)
         return rc;
     candidate *d_cand = (candidate *)ctx->d_scratch;
     unsigned long long *d_seen = (unsigned long long *)((uint8_t *)ctx->d_scratch + cand_bytes);
+    candidate *d_merged = (candidate *)((uint8_t *)d_seen + seen_bytes);
+    uint2 *d_aux = (uint2 *)((uint8_t *)d_merged + merged_bytes);
+    uint32_t *d_band_owner = (uint32_t *)((uint8_t *)d_aux + aux_bytes);
+    uint32_t *d_band_count = d_band_owner + band_slots;
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
+    if (merging) {
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_band_owner, 0xFF, band_slots * sizeof(uint32_t), ctx->stream));
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_band_count, 0, band_slots * sizeof(uint32_t), ctx->stream));
+    }
 
     filter_params P{};
     P.text = A.text->d;
@@ -1136,7 +1205,8 @@ int run_filter(const scan_args &A)
     // measured best: 8 waves per CU on the 1-byte text (HBM-bound), 16 on the 2-bit shadow (LDS/VALU-bound)
     const uint32_t threads =
         (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
-    const size_t lds = (size_t)F.lds_words * 4 + 16; // + the workgroup's span-dequeue slot
+    // + the workgroup's span-dequeue slot (4 words) + one candidate-chunk record (4 words) per wave
+    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * 16;
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
@@ -1296,10 +1366,47 @@ int run_filter(const scan_args &A)
         V.seg_offsets = d_seg;
         V.n_segments = A.n_segments;
     }
+    V.cand_counter = 1;
+    if (merging) {
+        merge_params M{};
+        M.cand = d_cand;
+        M.counters = H->d_count;
+        M.out_count = H->d_count + 3;
+        M.cand_cap = cand_cap;
+        M.m = ps->d_m;
+        M.k = ps->d_k;
+        M.surplus = ps->d_surplus;
+        M.key_len = ps->filter_key_len;
+        M.max_m = ps->max_m;
+        M.Bw = ps->max_k + 1;
+        M.table_mask = (uint32_t)(band_slots - 1);
+        M.hay_begin = A.ctx_begin;
+        M.seg_offsets = V.seg_offsets;
+        M.n_segments = V.n_segments;
+        M.aux = d_aux;
+        M.owner = d_band_owner;
+        M.count = d_band_count;
+        M.out = d_merged;
+        M.out_cap = 2 * cand_cap;
+        const dim3 mg(ctx->n_cu * 4), mb(256);
+        hipLaunchKernelGGL(merge_aux_kernel, mg, mb, 0, ctx->stream, M);
+        hipLaunchKernelGGL(merge_count_kernel, mg, mb, 0, ctx->stream, M);
+        hipLaunchKernelGGL(merge_select_kernel, mg, mb, 0, ctx->stream, M);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        V.cand = d_merged;
+        V.cand_cap = 2 * cand_cap;
+        V.cand_counter = 3;
+        V.max_span = M.Bw + ps->max_k;
+    }
     uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
-    if (nwn > 8)
-        nwn = ps->NW; // power of two beyond 8 words
-    launch_verify(nwn, V, dim3(ctx->n_cu * 4), ctx->stream);
+    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-candidate kernel
+    if (ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min) {
+        launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 4), ctx->stream);
+    } else {
+        if (nwn > 8)
+            nwn = ps->NW; // power of two beyond 8 words
+        launch_verify(nwn, V, dim3(ctx->n_cu * 4), ctx->stream);
+    }
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
     H->cand_cap = cand_cap;
@@ -1415,7 +1522,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         if (rc != SPM_OK)
             return rc;
         // overflow check needs the counters: one small D2H copy; on overflow re-run brute force
-        unsigned long long c[4] = {0, 0, 0, 0};
+        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [1] candidate slots drawn, [3] bands, [5] real candidates
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (c[1] > H->cand_cap && c[2] == 0 && c[1] <= (1ull << 25) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
@@ -1430,7 +1537,8 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             H->stats.main_launches = (uint32_t)patterns->fidx.size();
         }
-        H->stats.n_candidates = c[1];
+        H->stats.n_candidates = c[5];
+        H->stats.n_bands = (uint32_t)c[3];
         if (c[1] <= H->cand_cap)
             patterns->cand_hint = std::max<uint64_t>(patterns->cand_hint, c[1]);
         if (c[1] > H->cand_cap || c[2] != 0) {
@@ -1507,8 +1615,6 @@ static int hits_count(spm_hits *h)
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         h->n = c[0];
-        if (h->stats.engine_used == SPM_ENGINE_FILTER)
-            h->stats.n_candidates = c[1];
         h->counted = true;
     }
     if (h->n > h->cap) {
@@ -1708,17 +1814,19 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
         stats[2] = keys_total;
         uint64_t expect = 0;
         for (uint32_t p = 0; p < n_patterns; ++p)
-            expect += (uint64_t)(ps.k[p] + 1) * S;
+            expect += (uint64_t)plan_seeds((uint32_t)ps.m[p], ps.is_myers() ? (uint32_t)ps.k[p] : 0).n * S;
         if (expect != keys_total)
             return SPM_E_INVALID;
     }
     size_t fi = 0;
     uint64_t in_pass = 0;
     for (uint32_t p = 0; p < n_patterns; ++p) {
-        const uint32_t m = (uint32_t)ps.m[p], kk = (uint32_t)ps.k[p], q = m / (kk + 1);
+        const uint32_t m = (uint32_t)ps.m[p], kk = (uint32_t)ps.k[p];
+        const seed_plan sp = plan_seeds(m, ps.is_myers() ? kk : 0);
+        const uint32_t q = sp.q;
         if (S > q - (ps.filter_key_len - 1))
             return SPM_E_INVALID; // sampling would miss occurrences
-        const uint64_t mine = (uint64_t)(kk + 1) * S;
+        const uint64_t mine = (uint64_t)sp.n * S;
         while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
             if (in_pass != ps.fidx[fi].n_keys)
                 return SPM_E_INVALID;
@@ -1730,7 +1838,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
         in_pass += mine;
         const filter_index &F = ps.fidx[fi];
         const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
-        for (uint32_t j = 0; j <= kk; ++j)
+        for (uint32_t j = 0; j < sp.n; ++j)
             for (uint32_t r = 0; r < S; ++r) {
                 uint32_t key = 0;
                 for (uint32_t i = 0; i < ps.filter_key_len; ++i) {

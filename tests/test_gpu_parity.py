@@ -121,7 +121,10 @@ def _planted_config(spm, oracle, n_total, n_pat, L, kmax, seed_text=0x5EED0001, 
                                  ("myers", 64, 1, 64), ("myers", 1024, 10, 8),
                                  # short seeds -> keys of 12..15 symbols: q = 15 (the C5 shape), 16, 13, 12
                                  ("myers", 1024, 64, 8), ("myers", 60, 3, 100), ("myers", 64, 3, 64),
-                                 ("myers", 52, 3, 64), ("myers", 48, 3, 64), ("shiftor", 13, 0, 40)])
+                                 ("myers", 52, 3, 64), ("myers", 48, 3, 64), ("shiftor", 13, 0, 40),
+                                 # k >= 8: k + 2 seeds, candidates merged per diagonal band before verification
+                                 ("myers", 300, 10, 32), ("myers", 150, 8, 64), ("myers", 400, 20, 16),
+                                 ("myers", 2000, 100, 4)])
 def test_filter_engine_equals_brute_and_oracle(spm, ctx, oracle, cfg):
     """Seed filter + verification must return exactly the brute-force hit set (and the oracle's)."""
     algo, L, kmax, n_pat = cfg
@@ -145,6 +148,120 @@ def test_filter_engine_equals_brute_and_oracle(spm, ctx, oracle, cfg):
     want = _oracle_multi(oracle, algo, T, [needles[i] for i in sub], [kmax] * len(sub))
     got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(vf) if p in sub]
     assert sorted(got) == want
+
+
+@pytest.mark.parametrize("cfg", [(100, 3, 128, 4), (33, 1, 64, 4), (150, 3, 64, 5), (260, 10, 32, 4), (700, 30, 8, 4),
+                                 (1024, 64, 8, 4), (2000, 100, 4, 4), (300, 5, 16, 5)])
+def test_wave_per_candidate_verification(spm, ctx, oracle, cfg):
+    """The systolic verification kernel (one lane per 32-row block) forced for every needle length: group sizes 8, 16,
+    32 and 64 lanes, dna4 and dna5, raw and merged candidates.  Same hits as the brute engine and as the lane-per-
+    candidate kernel."""
+    L, kmax, n_pat, sigma = cfg
+    n = 1 << 21
+    rng = np.random.default_rng(L * 7 + kmax)
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    if sigma == 5:
+        T[T == 3] = 4                                   # dna5 ranks: A C G N T
+        T[rng.integers(0, n, 200)] = 3
+    needles = []
+    for i in range(n_pat):
+        o = int(rng.integers(0, n - 2 * L)) if i > 1 else (0 if i == 0 else n - L - kmax)
+        nd = list(T[o:o + L + kmax])
+        for j in range(int(rng.integers(0, kmax + 1))):
+            pos = int(rng.integers(0, L))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                nd[pos] = int(rng.choice([0, 1, 2, 4] if sigma == 5 else [0, 1, 2, 3]))
+            elif kind == 1:
+                del nd[pos]
+            else:
+                nd.insert(pos, int(rng.choice([0, 1, 2, 4] if sigma == 5 else [0, 1, 2, 3])))
+        nd = np.array(nd[:L], dtype=np.uint8)
+        if sigma == 5:
+            nd[nd == 3] = 0                             # needles with an N are not filterable
+        needles.append(nd)
+    text = ctx.upload(T, sigma=sigma)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=kmax, sigma=sigma)
+    assert ps.filterable
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22).view()
+    os.environ["SPM_HIP_VERIFY_WAVE_MIN_WORDS"] = "1"
+    try:
+        hw = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22)
+        assert hw.stats().fell_back == 0
+        hw = hw.view()
+        part = spm.scan(ctx, text, ps, 100001, n - 77, engine=spm.ENGINE_FILTER, left_context=True, max_hits=1 << 22).view()
+    finally:
+        del os.environ["SPM_HIP_VERIFY_WAVE_MIN_WORDS"]
+    os.environ["SPM_HIP_VERIFY_WAVE_MIN_WORDS"] = "0"
+    try:
+        hl = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22).view()
+    finally:
+        del os.environ["SPM_HIP_VERIFY_WAVE_MIN_WORDS"]
+    assert len(hb) >= n_pat // 2 and np.array_equal(hw, hb) and np.array_equal(hl, hb)
+    pb = spm.scan(ctx, text, ps, 100001, n - 77, engine=spm.ENGINE_BRUTE, left_context=True, max_hits=1 << 22).view()
+    assert np.array_equal(part, pb)
+    want = _oracle_multi(oracle, "myers", T, needles[:3], [kmax] * 3) if sigma == 4 else None
+    if want is not None:
+        assert [h for h in _hits_list(hw) if h[0] < 3] == want
+
+
+def test_candidate_merging_with_clustered_indels(spm, ctx, oracle):
+    """k >= 8: occurrences whose k edits are insertions / deletions bunched together (the intact seeds sit on diagonals
+    up to k apart), occurrences at the very start and end of the haystack, a tandem repeat (many seed hits per band)
+    and sub-ranges with left context.  Filter (merged bands) == brute == oracle; fewer bands than candidates."""
+    rng = np.random.default_rng(99)
+    n, L, k = 1 << 20, 360, 12
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    unit = rng.integers(0, 4, 45, dtype=np.uint8)
+    T[500000:500000 + 45 * 40] = np.tile(unit, 40)
+    needles = []
+    for i in range(24):
+        if i == 0:
+            src = T[:L + k].copy()                      # occurrence at the haystack start
+        elif i == 1:
+            src = T[n - L - k:].copy()                  # ... and at its end
+        elif i == 2:
+            src = T[500000 + 7:500000 + 7 + L + k].copy()   # inside the repeat
+        else:
+            o = int(rng.integers(1000, n - 2 * L))
+            src = T[o:o + L + k].copy()
+        nd = list(src)
+        e = int(rng.integers(0, k + 1))
+        at = int(rng.integers(10, L - 40))
+        for j in range(e):                              # bunched edits: all within ~30 symbols
+            kind = (i + j) % 3
+            pos = at + int(rng.integers(0, 30))
+            if kind == 0:
+                nd[pos] = (nd[pos] + 1) & 3
+            elif kind == 1:
+                del nd[pos]
+            else:
+                nd.insert(pos, int(rng.integers(0, 4)))
+        needles.append(np.array(nd[:L], dtype=np.uint8))
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    assert ps.filterable
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22)
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22)
+    st = hf.stats()
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
+    assert 0 < st.n_bands < st.n_candidates
+    assert np.array_equal(hf.view(), hb.view())
+    assert len(set(hb.view()["pattern"].tolist())) == len(needles)
+    want = _oracle_multi(oracle, "myers", T, needles[:6], [k] * 6)
+    assert [h for h in _hits_list(hf.view()) if h[0] < 6] == want
+    # sub-range with left context, and a cold-started sub-range
+    for lo, hi, lc in ((123457, 700001, True), (499000, 503000, False)):
+        a = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=lc, max_hits=1 << 22)
+        b = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=lc, max_hits=1 << 22)
+        assert np.array_equal(a.view(), b.view())
+    # merging switched off gives the same hits (k + 2 seeds, every candidate verified on its own)
+    os.environ["SPM_HIP_FILTER_MERGE"] = "0"
+    try:
+        hn = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22)
+        assert hn.stats().n_bands == 0 and np.array_equal(hn.view(), hb.view())
+    finally:
+        del os.environ["SPM_HIP_FILTER_MERGE"]
 
 
 def test_left_context_sharding_equals_whole_scan(spm, ctx, oracle):

@@ -48,6 +48,12 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
     assert rc == 0 and st["passes"] == 1 and (st["key_len"], st["stride"]) == (15, 2)   # q = 64 / 4 = 16
+    # needles with k >= 8 carry k + 2 seeds (two intact seeds per occurrence: candidate merging)
+    assert st["keys"] == (4 + 4 + 6 + 12 + 42) * 2 and st["missing"] == 0
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 1024, dtype=np.uint8)], 64)
+    assert rc == 0 and st["missing"] == 0 and st["keys"] == 66 * 2 and (st["key_len"], st["stride"]) == (14, 2)
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 100, dtype=np.uint8)], 7)       # q = 12, k + 1 seeds
+    assert rc == 0 and st["missing"] == 0 and st["keys"] == 8 and (st["key_len"], st["stride"]) == (12, 1)
     # short seeds: q = 15 (|P| = 60, k = 3 and the C5 shape |P| = 1024, k = 64) -> 14-symbol keys at stride 2
     rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8) for _ in range(100)], 3)
     assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and (st["key_len"], st["stride"]) == (14, 2)
