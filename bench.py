@@ -92,7 +92,8 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
     if args.needles is not None:
         n_pat = args.needles
     n_hap = 64
-    ref_len = int(gib * 2**30) // 10000 * 10000
+    # chromosome length: whole variant blocks (10 000) and whole KiB, so rank * ref_len is a valid generator offset
+    ref_len = max(640000, int(gib * 2**30) // 640000 * 640000)
     engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
     mix = S.capi.lib().spm_hip_mix64
     ref = ctx.generate(SEED_TEXT, rank * ref_len, ref_len)

@@ -13,9 +13,11 @@ src, dst = "gpurun_out", os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 f = glob.glob(f"{src}/prof_c3/*/*_kernel_stats.csv")[0]
 shutil.copy(f, f"{dst}/c3_16GiB_kernel_stats_{tag}.csv")
-for name in ("bench_c3", "bench_c2", "bench_c4", "bench_2rank_gloo"):
+for name in ("bench_c3", "bench_c2", "bench_c4", "bench_c5", "bench_2rank_gloo", "bench_c5_2rank_gloo"):
     if os.path.exists(f"{src}/{name}.json"):
         shutil.copy(f"{src}/{name}.json", f"{dst}/{name}_{tag}.json")
+for f5 in glob.glob(f"{src}/prof_c5/*/*_kernel_stats.csv"):
+    shutil.copy(f5, f"{dst}/c5_kernel_stats_{tag}.csv")
 out = {}
 for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")[0]
