@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/spm_hip.h"
@@ -43,6 +44,7 @@ struct spm_ctx
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
     std::vector<hits_block> pool;
+    std::vector<std::pair<void *, uint64_t>> jst_pool; // record buffers of journaled-sequence searches (pointer, capacity)
 };
 
 struct spm_text

@@ -546,6 +546,10 @@ struct spm_jst
     uint32_t *d_ctx_block = nullptr, *d_ctx_owned = nullptr;
     spm_text *ctx_text = nullptr;
     spm_jst_stats stats{};
+    // (record buffers of the searches are recycled through the context: a 200 MB hipMalloc / hipFree pair per search
+    // cost ~0.3 ms)
+    unsigned long long *d_fan_count = nullptr;
+    hipEvent_t fan_ev[2] = {nullptr, nullptr};
 
     spm_hip::jst_dev dev() const
     {
@@ -595,6 +599,7 @@ struct spm_jst_hits
 {
     spm_ctx *ctx = nullptr;
     spm_jst_hit *d = nullptr;
+    uint64_t cap = 0;
     uint64_t n = 0;
     bool sorted = false;
     std::vector<spm_jst_hit> host;
@@ -688,6 +693,11 @@ extern "C" void spm_hip_jst_destroy(spm_jst *J)
     hipSetDevice(J->ctx->device);
     hipStreamSynchronize(J->ctx->stream);
     J->free_index();
+    hipFree(J->d_fan_count);
+    if (J->fan_ev[0]) {
+        hipEventDestroy(J->fan_ev[0]);
+        hipEventDestroy(J->fan_ev[1]);
+    }
     hipFree(J->d_pos);
     hipFree(J->d_aoff);
     hipFree(J->d_rlen);
@@ -899,7 +909,12 @@ extern "C" void spm_hip_jst_hits_destroy(spm_jst_hits *h)
 {
     if (!h)
         return;
-    hipFree(h->d);
+    if (h->d) {
+        if (h->ctx && h->ctx->jst_pool.size() < 4)
+            h->ctx->jst_pool.push_back({h->d, h->cap});
+        else
+            hipFree(h->d);
+    }
     delete h;
 }
 
@@ -964,13 +979,23 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
     J->stats.segment_hits = n_seg_hits;
     J->stats.fell_back = ss.fell_back;
     J->stats.candidates = ss.n_candidates;
-    unsigned long long *d_count = nullptr;
-    SPM_HIP_CHECK(ctx, hipMalloc(&R->d, out_cap * sizeof(spm_jst_hit)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&d_count, 8));
+    for (size_t i = 0; i < ctx->jst_pool.size(); ++i)
+        if (ctx->jst_pool[i].second == out_cap) {
+            R->d = static_cast<spm_jst_hit *>(ctx->jst_pool[i].first);
+            ctx->jst_pool.erase(ctx->jst_pool.begin() + (long)i);
+            break;
+        }
+    if (!R->d)
+        SPM_HIP_CHECK(ctx, hipMalloc(&R->d, out_cap * sizeof(spm_jst_hit)));
+    R->cap = out_cap;
+    if (!J->d_fan_count) {
+        SPM_HIP_CHECK(ctx, hipMalloc(&J->d_fan_count, 8));
+        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[0]));
+        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[1]));
+    }
+    unsigned long long *d_count = J->d_fan_count;
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream));
-    hipEvent_t e0, e1;
-    SPM_HIP_CHECK(ctx, hipEventCreate(&e0));
-    SPM_HIP_CHECK(ctx, hipEventCreate(&e1));
+    hipEvent_t e0 = J->fan_ev[0], e1 = J->fan_ev[1];
     SPM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
     if (n_seg_hits) {
         jst_fan_params F{};
@@ -996,9 +1021,6 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
     SPM_HIP_CHECK(ctx, hipMemcpyAsync(&n_out, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     hipEventElapsedTime(&J->stats.ms_fanout, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(d_count);
     if (n_out > out_cap) {
         SPM_SET_ERR(ctx, "journaled-sequence search produced %llu hits but the buffer holds %llu; raise "
                          "spm_scan_opts.max_hits", n_out, (unsigned long long)out_cap);

@@ -698,6 +698,8 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
             if (b.ev[e])
                 hipEventDestroy(b.ev[e]);
     }
+    for (auto &b : ctx->jst_pool)
+        hipFree(b.first);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
