@@ -241,6 +241,7 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
         "verify_ms_per_step": ms_verify / args.steps,
         "fanout_ms_per_step": ms_fan / args.steps,
         "candidates": int(s1.candidates),
+        "bands_verified": int(s1.bands),
         "fell_back": int(s1.fell_back),
         "lane_steps_per_s": n_pat * hap_sym / step_s,
         "reference_equivalent_traffic_GBps": n_pat * hap_sym / step_s / 1e9,

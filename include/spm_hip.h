@@ -218,7 +218,8 @@ typedef struct spm_jst_stats {
     uint32_t main_launches;
     uint32_t fell_back;         /* last search: 1 if the seed filter overflowed and the brute engine re-ran the scan */
     uint64_t segment_hits;      /* last search: hits in context coordinates, before the fan-out */
-    uint64_t candidates;        /* last search: seed-filter candidates verified */
+    uint64_t candidates;        /* last search: seed-filter candidates */
+    uint64_t bands;             /* last search: diagonal bands verified after candidate merging (0: not merged) */
 } spm_jst_stats;
 
 /* `reference` must stay alive as long as the tree (it is not copied). */

@@ -79,6 +79,7 @@ class JstStats(C.Structure):
         ("fell_back", C.c_uint32),
         ("segment_hits", C.c_uint64),
         ("candidates", C.c_uint64),
+        ("bands", C.c_uint64),
     ]
 
 

@@ -1114,6 +1114,7 @@ struct merge_params
     uint2 *aux;      // per candidate: {segment, primary band}; segment 0xFFFFFFFF = dropped
     uint32_t *owner; // band table: (candidate << 1 | secondary) of the first arrival, 0xFFFFFFFF = empty
     uint32_t *count; // seed hits per band
+    uint2 *own_slot; // per candidate: the table slots it claimed (primary, secondary band), 0xFFFFFFFF = none
     candidate *out;
     uint64_t out_cap;
 };
@@ -1157,52 +1158,64 @@ __global__ void merge_count_kernel(const merge_params P)
         n = P.cand_cap;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint2 a = P.aux[i];
-        if (a.x == 0xFFFFFFFFu)
-            continue;
-        const candidate c = P.cand[i];
-        const uint32_t pat = c.val >> 11;
-        const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
-        const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
-        // band b covers diagonals [b*Bw, (b+1)*Bw + k]: the primary band, and the one before it if this diagonal
-        // still lies in its k-wide extension
-        const bool also_prev = a.y > 0 && dr - (int64_t)a.y * P.Bw <= (int64_t)P.k[pat];
-        for (uint32_t sec = 0; sec <= (also_prev ? 1u : 0u); ++sec) {
-            const uint32_t band = a.y - sec;
-            uint32_t s = (uint32_t)mix64(((uint64_t)pat << 40) ^ ((uint64_t)a.x << 17) ^ band) & P.table_mask;
-            while (true) {
-                uint32_t o = atomicCAS(&P.owner[s], 0xFFFFFFFFu, (uint32_t)(i << 1) | sec);
-                if (o == 0xFFFFFFFFu)
-                    o = (uint32_t)(i << 1) | sec;
-                const uint2 b = P.aux[o >> 1];
-                if ((P.cand[o >> 1].val >> 11) == pat && b.x == a.x && b.y - (o & 1u) == band) {
-                    atomicAdd(&P.count[s], 1u);
-                    break;
+        uint32_t claimed[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (a.x != 0xFFFFFFFFu) {
+            const candidate c = P.cand[i];
+            const uint32_t pat = c.val >> 11;
+            const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
+            const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
+            // band b covers diagonals [b*Bw, (b+1)*Bw + k]: the primary band, and the one before it if this diagonal
+            // still lies in its k-wide extension
+            const bool also_prev = a.y > 0 && dr - (int64_t)a.y * P.Bw <= (int64_t)P.k[pat];
+            for (uint32_t sec = 0; sec <= (also_prev ? 1u : 0u); ++sec) {
+                const uint32_t band = a.y - sec;
+                const uint32_t me = (uint32_t)(i << 1) | sec;
+                uint32_t s = (uint32_t)mix64(((uint64_t)pat << 40) ^ ((uint64_t)a.x << 17) ^ band) & P.table_mask;
+                while (true) {
+                    uint32_t o = atomicCAS(&P.owner[s], 0xFFFFFFFFu, me);
+                    if (o == 0xFFFFFFFFu)
+                        o = me;
+                    const uint2 b = P.aux[o >> 1];
+                    if ((P.cand[o >> 1].val >> 11) == pat && b.x == a.x && b.y - (o & 1u) == band) {
+                        atomicAdd(&P.count[s], 1u);
+                        if (o == me)
+                            claimed[sec] = s;
+                        break;
+                    }
+                    s = (s + 1) & P.table_mask;
                 }
-                s = (s + 1) & P.table_mask;
             }
         }
+        P.own_slot[i] = make_uint2(claimed[0], claimed[1]);
     }
 }
 
+// one thread per candidate: the claimer of a band emits it if the band collected enough seed hits
 __global__ void merge_select_kernel(const merge_params P)
 {
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= P.table_mask; s += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t o = P.owner[s];
-        if (o == 0xFFFFFFFFu)
+    unsigned long long n = P.counters[1];
+    if (n > P.cand_cap)
+        n = P.cand_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 mine = P.own_slot[i];
+        if (mine.x == 0xFFFFFFFFu && mine.y == 0xFFFFFFFFu)
             continue;
-        const uint32_t pat = P.cand[o >> 1].val >> 11;
-        if (P.count[s] < P.surplus[pat])
-            continue;
-        const uint2 a = P.aux[o >> 1];
-        const uint32_t band = a.y - (o & 1u);
+        const uint32_t pat = P.cand[i].val >> 11;
+        const uint2 a = P.aux[i];
         const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
-        const unsigned long long idx = atomicAdd(P.out_count, 1ull);
-        if (idx < P.out_cap) {
-            candidate c;
-            c.t = (uint64_t)(sb - (int64_t)P.max_m + (int64_t)band * P.Bw); // first diagonal of the band
-            c.val = (pat << 11) | (P.Bw + (uint32_t)P.k[pat]);                 // its last diagonal: + Bw + k
-            c.pad = a.x + 1;
-            P.out[idx] = c;
+        for (uint32_t sec = 0; sec < 2; ++sec) {
+            const uint32_t s = sec ? mine.y : mine.x;
+            if (s == 0xFFFFFFFFu || P.count[s] < P.surplus[pat])
+                continue;
+            const uint32_t band = a.y - sec;
+            const unsigned long long idx = atomicAdd(P.out_count, 1ull);
+            if (idx < P.out_cap) {
+                candidate c;
+                c.t = (uint64_t)(sb - (int64_t)P.max_m + (int64_t)band * P.Bw); // first diagonal of the band
+                c.val = (pat << 11) | (P.Bw + (uint32_t)P.k[pat]);                 // its last diagonal: + Bw + k
+                c.pad = a.x + 1;
+                P.out[idx] = c;
+            }
         }
     }
 }

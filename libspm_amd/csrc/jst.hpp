@@ -979,6 +979,7 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
     J->stats.segment_hits = n_seg_hits;
     J->stats.fell_back = ss.fell_back;
     J->stats.candidates = ss.n_candidates;
+    J->stats.bands = ss.n_bands;
     for (size_t i = 0; i < ctx->jst_pool.size(); ++i)
         if (ctx->jst_pool[i].second == out_cap) {
             R->d = static_cast<spm_jst_hit *>(ctx->jst_pool[i].first);

@@ -1158,7 +1158,7 @@ int run_filter(const scan_args &A)
     while (merging && band_slots < 4 * cand_cap)
         band_slots <<= 1;
     const size_t merged_bytes = merging ? 2 * cand_bytes : 0;
-    const size_t aux_bytes = merging ? cand_cap * sizeof(uint2) : 0;
+    const size_t aux_bytes = merging ? 2 * cand_cap * sizeof(uint2) : 0; // {segment, band} + the table slots claimed
     const size_t table_bytes = merging ? band_slots * 2 * sizeof(uint32_t) : 0;
     int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes);
     if (rc != SPM_OK)
@@ -1369,6 +1369,9 @@ int run_filter(const scan_args &A)
         V.n_segments = A.n_segments;
     }
     V.cand_counter = 1;
+    uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
+    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-candidate kernel
+    const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min;
     if (merging) {
         merge_params M{};
         M.cand = d_cand;
@@ -1380,12 +1383,19 @@ int run_filter(const scan_args &A)
         M.surplus = ps->d_surplus;
         M.key_len = ps->filter_key_len;
         M.max_m = ps->max_m;
-        M.Bw = ps->max_k + 1;
+        // band width: wider bands mean fewer occurrences whose seeds straddle two bands (each is then verified twice)
+        // at the price of more end positions per verification; 4(k+1) measured best for |P| = 1024, k = 64
+        // (the lane-per-candidate kernel keeps its end-position slots per thread: narrow bands there)
+        const uint32_t bw_factor = use_wave ? (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_BAND_FACTOR", 4)) : 1u;
+        M.Bw = (ps->max_k + 1) * bw_factor;
+        if (M.Bw + ps->max_k > 2047)
+            M.Bw = ps->max_k + 1;
         M.table_mask = (uint32_t)(band_slots - 1);
         M.hay_begin = A.ctx_begin;
         M.seg_offsets = V.seg_offsets;
         M.n_segments = V.n_segments;
         M.aux = d_aux;
+        M.own_slot = d_aux + cand_cap;
         M.owner = d_band_owner;
         M.count = d_band_count;
         M.out = d_merged;
@@ -1400,10 +1410,9 @@ int run_filter(const scan_args &A)
         V.cand_counter = 3;
         V.max_span = M.Bw + ps->max_k;
     }
-    uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
-    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-candidate kernel
-    if (ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min) {
-        launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 4), ctx->stream);
+    if (use_wave) {
+        // one verification is a ~1400-step serial chain: enough waves that every band gets its own right away
+        launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
     } else {
         if (nwn > 8)
             nwn = ps->NW; // power of two beyond 8 words

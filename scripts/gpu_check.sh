@@ -20,5 +20,5 @@ import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         r=json.loads(l); j=r['journaled_sequence_tree']
-        print('c5 value', round(r['value'],1), 'ms', round(r['ms_per_step'],3), 'kernel', round(r['roofline']['kernel_ms'],3), 'frac', round(r['roofline']['frac'],4), 'hits', r['hits'], 'found', r['needles_found_on_their_haplotype'], 'sharing', round(j['sharing'],2), 'index_ms', round(j['index_ms_rank0'],1), 'verify', round(r['verify_ms_per_step'],3), 'fan', round(r['fanout_ms_per_step'],3), r.get('brute_force_engine'))
+        print('c5 value', round(r['value'],1), 'ms', round(r['ms_per_step'],3), 'kernel', round(r['roofline']['kernel_ms'],3), 'frac', round(r['roofline']['frac'],4), 'hits', r['hits'], 'found', r['needles_found_on_their_haplotype'], 'sharing', round(j['sharing'],2), 'index_ms', round(j['index_ms_rank0'],1), 'verify', round(r['verify_ms_per_step'],3), 'fan', round(r['fanout_ms_per_step'],3), 'cand', r['candidates'], 'bands', r['bands_verified'], r.get('brute_force_engine'))
 " || tail -5 gpurun_out/c5.err
