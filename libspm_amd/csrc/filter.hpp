@@ -737,6 +737,8 @@ struct verify_params
     unsigned long long *overflow; // counters[2]
     const uint64_t *seg_offsets;  // segmented haystacks: n_segments+1 ascending offsets, or nullptr
     uint64_t n_segments;
+    const uint32_t *seg_owned;    // optional, per segment: only hits whose last symbol lies at or behind this offset
+                                  // are wanted (journaled-sequence contexts: the symbols before it are left context)
 };
 
 // One lane per candidate.  Same recurrence and layout as the brute kernel (32-bit words, v_bitop3, needles
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
             const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
             if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
                 continue; // the key window straddles two haystacks
-            own_b = sb;
+            own_b = P.seg_owned ? sb + (int64_t)P.seg_owned[lo] : sb;
             own_e = se;
             hay_b = sb;
         }
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
                 if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
                     active = false;
-                own_b = sb;
+                own_b = P.seg_owned ? sb + (int64_t)P.seg_owned[lo] : sb;
                 own_e = se;
                 hay_b = sb;
             }
@@ -1115,6 +1117,7 @@ struct merge_params
     uint32_t *owner; // band table: (candidate << 1 | secondary) of the first arrival, 0xFFFFFFFF = empty
     uint32_t *count; // seed hits per band
     uint2 *own_slot; // per candidate: the table slots it claimed (primary, secondary band), 0xFFFFFFFF = none
+    const uint32_t *seg_owned; // optional (verify_params::seg_owned): bands that end before it are not verified
     candidate *out;
     uint64_t out_cap;
 };
@@ -1208,6 +1211,10 @@ __global__ void merge_select_kernel(const merge_params P)
             if (s == 0xFFFFFFFFu || P.count[s] < P.surplus[pat])
                 continue;
             const uint32_t band = a.y - sec;
+            const int64_t d_lo = sb - (int64_t)P.max_m + (int64_t)band * P.Bw;
+            // last end position the band can produce: diagonal d_lo + Bw + k, needle length m, k more symbols
+            if (P.seg_owned && d_lo + (int64_t)P.Bw + 2 * (int64_t)P.k[pat] + (int64_t)P.m[pat] <= sb + (int64_t)P.seg_owned[a.x])
+                continue; // everything this band can report ends inside the haystack's unwanted prefix
             const unsigned long long idx = atomicAdd(P.out_count, 1ull);
             if (idx < P.out_cap) {
                 candidate c;

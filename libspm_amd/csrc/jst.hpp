@@ -959,8 +959,9 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
         return SPM_OK;
     }
     spm_hits *seg = nullptr;
+    // the verification stage skips end positions inside a context's left context (the fan-out would drop them)
     int rc = scan_impl(ctx, J->ctx_text, 0, J->ctx_bytes, patterns, &o, nullptr, nullptr, nullptr, J->n_ctx, &seg,
-                       J->d_ctx_off);
+                       J->d_ctx_off, J->d_ctx_owned);
     if (rc != SPM_OK)
         return rc;
     std::unique_ptr<spm_hits, void (*)(spm_hits *)> S(seg, spm_hip_hits_destroy);

@@ -895,6 +895,7 @@ struct scan_args
     const uint64_t *seg_offsets = nullptr; // host; n_segments + 1 entries
     uint64_t n_segments = 0;
     const uint64_t *d_seg_offsets = nullptr; // the same table already resident on the device (journaled-sequence index)
+    const uint32_t *d_seg_owned = nullptr;   // optional per-segment offset of the first wanted end symbol (filter engine)
     uint64_t cand_cap_override = 0;          // retry after a candidate overflow: the count the first attempt needed
     std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
 };
@@ -1358,6 +1359,7 @@ int run_filter(const scan_args &A)
     if (A.d_seg_offsets) {
         V.seg_offsets = A.d_seg_offsets;
         V.n_segments = A.n_segments;
+        V.seg_owned = A.d_seg_owned;
     } else if (A.seg_offsets) {
         uint64_t *d_seg = nullptr;
         SPM_HIP_CHECK(ctx, hipMalloc(&d_seg, (A.n_segments + 1) * sizeof(uint64_t)));
@@ -1396,6 +1398,7 @@ int run_filter(const scan_args &A)
         M.n_segments = V.n_segments;
         M.aux = d_aux;
         M.own_slot = d_aux + cand_cap;
+        M.seg_owned = V.seg_owned;
         M.owner = d_band_owner;
         M.count = d_band_count;
         M.out = d_merged;
@@ -1428,7 +1431,8 @@ int run_filter(const scan_args &A)
 
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
-                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets = nullptr);
+                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets = nullptr,
+                     const uint32_t *d_seg_owned = nullptr);
 
 extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end,
                             const spm_patterns *patterns, const spm_scan_opts *opts_in, const void *state_in,
@@ -1460,7 +1464,7 @@ extern "C" int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const u
 
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
-                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets)
+                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets, const uint32_t *d_seg_owned)
 {
     if (!ctx || !text || !patterns || !out || begin > end || end > text->n) {
         SPM_SET_ERR(ctx, "spm_hip_scan: invalid argument");
@@ -1505,6 +1509,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
     A.seg_offsets = seg_offsets;
     A.n_segments = n_segments;
     A.d_seg_offsets = d_seg_offsets;
+    A.d_seg_owned = d_seg_owned;
 
     const bool has_state = state_in != nullptr;
     const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && !patterns->fidx.empty());
