@@ -66,6 +66,7 @@ struct filter_params
     uint32_t n_probes;        // Bloom probes per key
     uint32_t span_chunks;     // 1-KiB chunks per span
     uint32_t dynamic;         // 1: waves draw spans from counters[4] instead of a static round-robin
+    uint32_t queue_cap;       // 0: resolve survivors on the spot; else they are queued in LDS (strides 1 and 2)
     uint32_t key_len;         // H: symbols per key (12..16); windows are H symbols, keys 2H bits
     uint32_t key_mask;        // (1 << 2H) - 1
     uint32_t hash_variant;    // 0/1: Bloom cascade with mul / xor-shift hashes, 2: perfect-hash fingerprints
@@ -221,6 +222,122 @@ __device__ __forceinline__ void cand_close(const filter_params &P, const uint32_
     }
 }
 
+// Level 2 for one survivor per lane (wave-uniform call; `probing` marks the lanes that hold one): probe the exact key
+// table, append every (needle, offset) the key belongs to as a candidate.
+template <int S>
+__device__ __forceinline__ void resolve_survivors(const filter_params &P, bool probing, uint32_t key, uint64_t t,
+                                                  uint32_t lane, const uint32_t *lds)
+{
+    bool emit = false;
+    uint32_t val = 0;
+    uint32_t slot = ht_hash(key) & P.ht_mask;
+    while (__ballot(probing) != 0) {
+        emit = false;
+        if (probing) {
+            const uint2 e = P.ht[slot];
+            if (e.y == kHtEmpty) {
+                probing = false;
+            } else {
+                if (e.x == key) {
+                    emit = true;
+                    val = e.y;
+                }
+                slot = (slot + 1) & P.ht_mask;
+            }
+        }
+        const uint64_t m = __ballot(emit);
+        if (m != 0) {
+            const uint32_t n = __popcll(m);
+            if constexpr (S <= 2) {
+                // strides 1 and 2 (huge needle sets, short keys) see 10^5..10^6 survivors: slots come in chunks
+                uint32_t *ck = cand_chunk_of(P, lds);
+                uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
+                if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
+                    cand_close(P, ck, lane);
+                    const uint32_t size = n > kCandChunk ? n : kCandChunk;
+                    if (lane == 0) {
+                        const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
+                        ck[0] = (uint32_t)b;
+                        ck[1] = (uint32_t)(b >> 32);
+                        ck[3] = size;
+                    }
+                    used = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint64_t cbase = ((uint64_t)ck[1] << 32) | ck[0];
+                if (emit) {
+                    const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
+                    if (idx < P.cand_cap) {
+                        candidate c;
+                        c.t = t;
+                        c.val = val;
+                        c.pad = 0;
+                        P.cand[idx] = c;
+                    }
+                }
+                if (lane == 0)
+                    ck[2] = used + n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // the larger strides see a few thousand survivors per scan: one atomic per ballot is cheaper
+                // than carrying the chunk bookkeeping through the streaming kernel (measured: C3 2.49 vs 2.60 ms)
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader)
+                    base = atomicAdd(&P.counters[1], (unsigned long long)n);
+                base = __shfl(base, leader);
+                if (emit) {
+                    const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
+                    if (idx < P.cand_cap) {
+                        candidate c;
+                        c.t = t;
+                        c.val = val;
+                        c.pad = 0;
+                        P.cand[idx] = c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Strides 1 and 2 meet 10^5..10^6 survivors per scan.  Resolving each one where it turns up costs the whole wave an L2
+// round trip per survivor (~3 us); instead they are queued in LDS (key + text position) and resolved 64 at a time.
+// Per wave: {count, key[cap], t_lo[cap], t_hi[cap]} behind the chunk records.
+constexpr uint32_t kQueueCap = 96;
+constexpr uint32_t kQueueWords = 4 + 3 * kQueueCap; // per wave
+constexpr uint32_t kQueueLdsSlot = kCandLdsSlot + 4 * 16; // words after lds_words where the queues start
+
+__device__ __forceinline__ uint32_t *survivor_queue_of(const filter_params &P, const uint32_t *lds)
+{
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    return const_cast<uint32_t *>(lds) + P.lds_words + kQueueLdsSlot + kQueueWords * wave;
+}
+
+template <int S>
+__device__ __forceinline__ void drain_survivors(const filter_params &P, uint32_t lane, const uint32_t *lds)
+{
+    uint32_t *q = survivor_queue_of(P, lds);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(q[0]);
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t e = base + lane;
+        const bool have = e < n;
+        const uint32_t key = have ? q[4 + e] : 0u;
+        const uint64_t t = have ? (((uint64_t)q[4 + 2 * kQueueCap + e] << 32) | q[4 + kQueueCap + e]) : 0ull;
+        resolve_survivors<S>(P, have, key, t, lane, lds);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+        q[0] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Level 1 + level 2 on NWD 2-bit-packed words per lane (w[j] = 16 bases, prev[j] = the 16 bases before them).
 // PK selects how word j maps to a text position (1-byte text vs. packed shadow).
 // KM: keys shorter than 16 symbols (masked); only strides 1 and 2 ever carry such keys.
@@ -320,11 +437,8 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
     }
     // survivors: exact key table
     while (__ballot(pos_mask != 0) != 0) {
-        bool emit = false;
         uint64_t t = 0;
-        uint32_t val = 0;
         uint32_t key = 0;
-        uint32_t slot = 0;
         bool probing = false;
         if (pos_mask != 0) {
             const int bit = __ffs(pos_mask) - 1;
@@ -346,79 +460,33 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
             const int64_t ts = (int64_t)wpos - 16 + d;
             if (ts >= (int64_t)P.lo && (uint64_t)ts + P.key_len <= P.hi) {
                 t = (uint64_t)ts;
-                slot = ht_hash(key) & P.ht_mask;
                 probing = true;
             }
         }
-        while (__ballot(probing) != 0) {
-            emit = false;
-            if (probing) {
-                const uint2 e = P.ht[slot];
-                if (e.y == kHtEmpty) {
-                    probing = false;
-                } else {
-                    if (e.x == key) {
-                        emit = true;
-                        val = e.y;
-                    }
-                    slot = (slot + 1) & P.ht_mask;
-                }
-            }
-            const uint64_t m = __ballot(emit);
+        if (S <= 2 && P.queue_cap != 0) {
+            // queue them; the wave resolves 64 at a time
+            const uint64_t m = __ballot(probing);
             if (m != 0) {
+                uint32_t *q = survivor_queue_of(P, lds);
+                uint32_t qn = (uint32_t)__builtin_amdgcn_readfirstlane(q[0]);
                 const uint32_t n = __popcll(m);
-                if constexpr (S <= 2) {
-                    // strides 1 and 2 (huge needle sets, short keys) see 10^5..10^6 survivors: slots come in chunks
-                    uint32_t *ck = cand_chunk_of(P, lds);
-                    uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
-                    if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
-                        cand_close(P, ck, lane);
-                        const uint32_t size = n > kCandChunk ? n : kCandChunk;
-                        if (lane == 0) {
-                            const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
-                            ck[0] = (uint32_t)b;
-                            ck[1] = (uint32_t)(b >> 32);
-                            ck[3] = size;
-                        }
-                        used = 0;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const uint64_t cbase = ((uint64_t)ck[1] << 32) | ck[0];
-                    if (emit) {
-                        const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
-                        if (idx < P.cand_cap) {
-                            candidate c;
-                            c.t = t;
-                            c.val = val;
-                            c.pad = 0;
-                            P.cand[idx] = c;
-                        }
-                    }
-                    if (lane == 0)
-                        ck[2] = used + n;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                } else {
-                    // the larger strides see a few thousand survivors per scan: one atomic per ballot is cheaper
-                    // than carrying the chunk bookkeeping through the streaming kernel (measured: C3 2.49 vs 2.60 ms)
-                    const int leader = __ffsll((unsigned long long)m) - 1;
-                    unsigned long long base = 0;
-                    if ((int)lane == leader)
-                        base = atomicAdd(&P.counters[1], (unsigned long long)n);
-                    base = __shfl(base, leader);
-                    if (emit) {
-                        const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
-                        if (idx < P.cand_cap) {
-                            candidate c;
-                            c.t = t;
-                            c.val = val;
-                            c.pad = 0;
-                            P.cand[idx] = c;
-                        }
-                    }
+                if (qn + n > kQueueCap) {
+                    drain_survivors<S>(P, lane, lds);
+                    qn = 0;
                 }
+                if (probing) {
+                    const uint32_t e = qn + __popcll(m & ((1ull << lane) - 1));
+                    q[4 + e] = key;
+                    q[4 + kQueueCap + e] = (uint32_t)t;
+                    q[4 + 2 * kQueueCap + e] = (uint32_t)(t >> 32);
+                }
+                if (lane == 0)
+                    q[0] = qn + n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
+        } else {
+            resolve_survivors<S>(P, probing, key, t, lane, lds);
         }
     }
 }
@@ -469,6 +537,8 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
         ck[1] = 0;
         ck[2] = 0;
         ck[3] = 0; // size 0: the first survivor draws a chunk
+        if (P.queue_cap != 0)
+            lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
     __syncthreads();
 
@@ -570,8 +640,11 @@ __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P
         }
         sp += n_waves;
     }
-    if constexpr (S <= 2)
+    if constexpr (S <= 2) {
+        if (P.queue_cap != 0)
+            drain_survivors<S>(P, lane, lds);
         cand_close(P, cand_chunk_of(P, lds), lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -609,6 +682,8 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
         ck[1] = 0;
         ck[2] = 0;
         ck[3] = 0; // size 0: the first survivor draws a chunk
+        if (P.queue_cap != 0)
+            lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
     __syncthreads();
 
@@ -700,8 +775,11 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
         }
         sp += n_waves;
     }
-    if constexpr (S <= 2)
+    if constexpr (S <= 2) {
+        if (P.queue_cap != 0)
+            drain_survivors<S>(P, lane, lds);
         cand_close(P, cand_chunk_of(P, lds), lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1209,7 +1209,16 @@ int run_filter(const scan_args &A)
     const uint32_t threads =
         (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one candidate-chunk record (4 words) per wave
-    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * 16;
+    size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * 16;
+    // strides 1 and 2: survivors are queued in LDS and resolved 64 at a time, if the queues fit beside the table
+    P.queue_cap = 0;
+    {
+        const size_t with_queues = lds + (size_t)(threads / 64) * kQueueWords * 4;
+        if (F.stride <= 2 && with_queues <= 160 * 1024 && env_int("SPM_HIP_FILTER_QUEUE", 1) != 0) {
+            P.queue_cap = kQueueCap;
+            lds = with_queues;
+        }
+    }
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
