@@ -180,6 +180,37 @@ def test_device_jst_synthetic_c5_shape(spm, ctx, oracle):
     jst.close()
 
 
+def test_device_jst_dna5_reference(spm, ctx, oracle):
+    """A reference with N (dna5 ranks A C G N T): contexts inherit the alphabet, the seed filter masks windows with N."""
+    rng = np.random.default_rng(17)
+    n_ref, n_hap, L, k = 80_000, 20, 60, 2
+    ref = rng.integers(0, 4, n_ref, dtype=np.uint8)
+    ref[ref == 3] = 4
+    ref[rng.integers(0, n_ref, 60)] = 3
+    ref_text = ctx.upload(ref, sigma=5)
+    alleles, pool, cov = _random_alleles(rng, n_ref, n_hap, 300, 10)
+    pool[pool == 3] = 4
+    jst = spm.Jst(ctx, ref_text, alleles, pool, cov, n_hap)
+    haps = [_apply(ref, alleles, pool, cov, h) for h in range(n_hap)]
+    needles = []
+    while len(needles) < 16:
+        nd = _needles_from(rng, haps, 1, L, k)[0]
+        nd[nd == 3] = 0
+        needles.append(nd)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k, sigma=5)
+    assert ps.filterable
+    exp = []
+    for h, hp in enumerate(haps):
+        t = ctx.upload(hp, sigma=5)
+        v = spm.scan(ctx, t, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 20).view()
+        exp += [(h, int(a), int(b), int(c)) for a, b, c in zip(v["pos"], v["pattern"], v["score"])]
+        t.close()
+    jst.index(L + k, 256)
+    assert _got(jst.search(ps, max_hits=1 << 20)) == sorted(exp) and len(exp) > 0
+    assert jst.stats().engine_used == spm.ENGINE_FILTER
+    jst.close()
+
+
 def test_device_jst_rejects_what_it_cannot_index(spm, ctx, oracle):
     ref_text = ctx.upload(np.zeros(1000, dtype=np.uint8))
     al = np.array([(10, 5, 0, 0), (12, 1, 1, 0)], dtype=spm.ALLELE_DTYPE)      # SNP inside a deletion, shared haplotype
