@@ -7,20 +7,26 @@ import os
 import shutil
 import sys
 
+def newest(pattern):
+    """gpurun merges into gpurun_out/ without deleting earlier runs: take the most recent match."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "v5"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src, dst = "gpurun_out", os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-f = glob.glob(f"{src}/prof_c3/*/*_kernel_stats.csv")[0]
+f = newest(f"{src}/prof_c3/*/*_kernel_stats.csv")[0]
 shutil.copy(f, f"{dst}/c3_16GiB_kernel_stats_{tag}.csv")
 for name in ("bench_c3", "bench_c2", "bench_c4", "bench_c5", "bench_2rank_gloo", "bench_c5_2rank_gloo"):
     if os.path.exists(f"{src}/{name}.json"):
         shutil.copy(f"{src}/{name}.json", f"{dst}/{name}_{tag}.json")
-for f5 in glob.glob(f"{src}/prof_c5/*/*_kernel_stats.csv"):
+for f5 in newest(f"{src}/prof_c5/*/*_kernel_stats.csv"):
     shutil.copy(f5, f"{dst}/c5_kernel_stats_{tag}.csv")
 out = {}
 for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")[0]
+    f = newest(f"{src}/{d}/*/*_counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if "spm_hip" in r["Kernel_Name"]]
     with open(f"{dst}/c3_16GiB_pmc_{name}_{tag}.csv", "w") as g:
         w = csv.writer(g)
@@ -43,7 +49,7 @@ with open(f"{dst}/c3_16GiB_pmc_SQ_{tag}.csv", "w") as g:
     w = csv.writer(g)
     w.writerow(["kernel", "counter", "value", "duration_ns"])
     for d in ("pmc_sq", "pmc_sq2"):
-        f = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")[0]
+        f = newest(f"{src}/{d}/*/*_counter_collection.csv")[0]
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "seed_filter" in r["Kernel_Name"]:
@@ -57,7 +63,7 @@ brute = {}
 NB = 1 << 28
 for d, wl, n_pat, key in (("pmc_brute_c3", "c3", 1024, "c3"), ("pmc_brute_c3_full", "c3", 1024, "c3_full_width"),
                           ("pmc_brute_c2", "c2", 1024, "c2")):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{d}/*/*_counter_collection.csv")
     if not fs:
         continue
     rows = [r for r in csv.DictReader(open(fs[0])) if "brute_kernel" in r["Kernel_Name"] or "cutoff_kernel" in r["Kernel_Name"]]
