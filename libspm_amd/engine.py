@@ -112,7 +112,8 @@ class Text:
 
     def close(self):
         if self._h:
-            capi.lib().spm_hip_text_destroy(self._h)
+            if self.ctx._h:  # the C objects point at their context: once it is gone there is nothing left to release
+                capi.lib().spm_hip_text_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -143,7 +144,8 @@ class PatternSet:
 
     def close(self):
         if self._h:
-            capi.lib().spm_hip_patterns_destroy(self._h)
+            if self.ctx._h:  # the C objects point at their context: once it is gone there is nothing left to release
+                capi.lib().spm_hip_patterns_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -189,7 +191,8 @@ class Hits:
 
     def close(self):
         if self._h:
-            capi.lib().spm_hip_hits_destroy(self._h)
+            if self.ctx._h:  # the C objects point at their context: once it is gone there is nothing left to release
+                capi.lib().spm_hip_hits_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -314,7 +317,8 @@ class Jst:
 
     def close(self):
         if self._h:
-            capi.lib().spm_hip_jst_destroy(self._h)
+            if self.ctx._h:
+                capi.lib().spm_hip_jst_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -349,7 +353,8 @@ class JstHits:
 
     def close(self):
         if self._h:
-            capi.lib().spm_hip_jst_hits_destroy(self._h)
+            if self.ctx._h:
+                capi.lib().spm_hip_jst_hits_destroy(self._h)
             self._h = None
 
     def __del__(self):

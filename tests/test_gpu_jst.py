@@ -180,6 +180,32 @@ def test_device_jst_synthetic_c5_shape(spm, ctx, oracle):
     jst.close()
 
 
+def test_device_jst_two_filter_passes_with_merging(spm, ctx, oracle):
+    """800 needles |P| = 1024, k = 64: 52 800 seeds -> two seed-filter passes feeding one band-merging + wave-verification
+    stage over segmented contexts.  Equals per-haplotype brute-force scans."""
+    n_ref, n_hap, L, k = 150_000, 12, 1024, 64
+    rng = np.random.default_rng(23)
+    ref_text = ctx.generate(SEED_TEXT, 0, n_ref)
+    ref = ref_text.download(0, n_ref)
+    alleles, pool, cov = spm.synth_variants(SEED_TEXT, SEED_VAR, 0, n_ref, n_hap)
+    cov2 = cov.reshape(-1, 1)
+    jst = spm.Jst(ctx, ref_text, alleles, pool, cov2, n_hap)
+    haps = [_apply(ref, alleles, pool, cov2, h) for h in range(n_hap)]
+    needles = _needles_from(rng, haps, 800, L, k)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    assert ps.filterable
+    exp = _expected(spm, ctx, haps, ps, spm.ENGINE_BRUTE)
+    jst.index(L + k, 512)
+    h = jst.search_device(ps, max_hits=1 << 23)
+    got = _got(h.view())
+    h.close()
+    st = jst.stats()
+    assert st.engine_used == spm.ENGINE_FILTER and st.main_launches == 2 and st.fell_back == 0
+    assert 0 < st.bands < st.candidates
+    assert got == exp and len(exp) >= 800
+    jst.close()
+
+
 def test_device_jst_dna5_reference(spm, ctx, oracle):
     """A reference with N (dna5 ranks A C G N T): contexts inherit the alphabet, the seed filter masks windows with N."""
     rng = np.random.default_rng(17)
