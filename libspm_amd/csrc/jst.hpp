@@ -22,6 +22,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+// the ctypes binding (libspm_amd/capi.py) mirrors these layouts
+static_assert(sizeof(spm_jst_allele) == 24 && sizeof(spm_jst_hit) == 24 && sizeof(spm_jst_stats) == 104, "C ABI layout");
+
 namespace spm_hip
 {
 
