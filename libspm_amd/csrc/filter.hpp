@@ -7,21 +7,23 @@
 // MI355X formulation of that idea, arranged so that the text is streamed ONCE at HBM speed:
 //
 //   Pigeonhole: cut needle P (|P| = m, k errors) into k+1 disjoint seeds of q = floor(m/(k+1)) symbols.  Any
-//   occurrence with <= k edits contains at least one seed unedited.
+//   occurrence with <= k edits contains at least one seed unedited.  (Needles with k >= 8 get k+2 seeds: two of
+//   them survive, on diagonals <= k apart -- see "candidate merging" below.)
 //   Sampling:   an exact seed occurrence text[ts, ts+q) contains, for every stride S <= q-H+1, exactly one
 //   H-symbol window that starts at a text position t = 0 (mod S); it equals seed[r, r+H) for r = t-ts in [0,S).
 //   So it suffices to look at text windows at multiples of S and to index S shifted H-mers per seed.
-//   H = 16 symbols = one 32-bit key after 2-bit packing.
+//   H = 16 symbols = one 32-bit key after 2-bit packing (12..15 for seeds shorter than 17 symbols).
 //
 //   Level 1 (filter kernel, the streaming kernel): each lane loads 16 text bytes (one 16-byte coalesced load),
 //   packs them to 2 bits/base with 4 v_dot4_u32_u8, takes the previous lane's word through DPP wave_shr:1, forms
-//   the 16/S windows with v_alignbit and probes a Bloom bitmap held in LDS (cascade: later probes only run for
-//   survivors).  Survivors are looked up in an exact key table in HBM/L2 and emitted as candidates
-//   (text position, needle, needle offset) with a ballot/popc wave-aggregated append.
-//   Level 2 (verify kernel): one lane per candidate runs the same Myers recurrence as the brute kernel over the
-//   m+3k symbols around the candidate diagonal, cold-started m+k symbols before the first end position it is
-//   responsible for -- exact by the window property used for tiling.  Duplicates (several seeds of one
-//   occurrence) are removed with an atomicCAS hash set keyed by (needle, end).
+//   the 16/S windows with v_alignbit and looks them up in a perfect-hash fingerprint table held in LDS (two LDS
+//   reads per window; a Bloom cascade is kept as fallback).  Survivors are looked up in an exact key table in L2
+//   and emitted as candidates (text position, needle, needle offset).
+//   Level 2 (verification): the Myers recurrence over the m+3k symbols around the candidate diagonal, cold-started
+//   m+k symbols before the first end position it is responsible for -- exact by the window property used for
+//   tiling.  Short needles: one lane per candidate (verify_kernel); long needles: one lane per 32-row block
+//   (verify_wave_kernel).  Duplicates (several seeds of one occurrence) are removed with an atomicCAS hash set keyed
+//   by (needle, end).
 //
 // Exactness does not depend on the text being random: every true hit has a surviving seed, every candidate is
 // verified by the full recurrence.  Pathological inputs only cost time; if the candidate buffer overflows the
@@ -528,7 +530,7 @@ template <int S, int U, bool NT, int HV, int SIG, bool KM>
 __global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
-    // ---- stage the Bloom bitmap in LDS (once per workgroup; the grid is persistent) ----
+    // ---- stage the level-1 table in LDS (once per workgroup; the grid is persistent) ----
     for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
         lds[i] = P.bitmap[i];
     if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
