@@ -358,7 +358,7 @@ def main():
         engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
         max_hits = max(1 << 20, 16 * n_pat)
         # fused gather buffer: row 0 = [count, 0], rows 1.. = records; same fixed size on every rank
-        cap = 1 << 16
+        cap = 1 << 12   # small on purpose: the all-gather moves world x (cap + 1) x 16 bytes per step
         while cap < 8 * n_pat:
             cap <<= 1
         hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
