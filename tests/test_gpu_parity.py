@@ -550,6 +550,59 @@ def test_fuzz_engines_against_oracle(spm, ctx, oracle):
     assert n_filter >= 5
 
 
+def test_fuzz_long_needles_many_errors(spm, ctx, oracle):
+    """Randomised long needles with many errors (k + 2 seeds, band merging, wave-per-candidate verification, mixed
+    lengths and k in one set, short keys, sub-ranges with and without left context): filter == brute; a sample of
+    needles also against the oracle."""
+    rng = np.random.default_rng(int(os.environ.get("SPM_FUZZ_SEED", "777")))     # soak: SPM_FUZZ_ITERS=500 SPM_FUZZ_SEED=..
+    for it in range(int(os.environ.get("SPM_FUZZ_ITERS", "24"))):
+        n = int(rng.choice([1 << 16, 1 << 18, (1 << 20) + 77]))
+        T = rng.integers(0, 4, n, dtype=np.uint8)
+        if it % 6 == 0:                                  # low-complexity stretch: many seed hits per band
+            unit = rng.integers(0, 4, int(rng.integers(3, 40)), dtype=np.uint8)
+            reps = 4000 // len(unit)
+            T[n // 2:n // 2 + len(unit) * reps] = np.tile(unit, reps)
+        n_pat = int(rng.choice([1, 3, 8, 20]))
+        needles, ks = [], []
+        for i in range(n_pat):
+            m = int(rng.choice([120, 200, 256, 257, 400, 777, 1024, 1500, 2047]))
+            m = min(m, n // 4)
+            kmax = max(1, m // 13 - 1)                   # keeps floor(m / (k + 1)) >= 12: filterable
+            k = int(rng.integers(1, kmax + 1)) if it % 4 else kmax
+            o = int(rng.integers(0, n - m - k - 1)) if i else int(rng.choice([0, n - m - k - 1]))
+            nd = list(T[o:o + m + k])
+            for _ in range(int(rng.integers(0, k + 1))):
+                pos = int(rng.integers(0, m))
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    nd[pos] = int(rng.integers(0, 4))
+                elif kind == 1:
+                    del nd[pos]
+                else:
+                    nd.insert(pos, int(rng.integers(0, 4)))
+            needles.append(np.array(nd[:m], dtype=np.uint8))
+            ks.append(k)
+        text = ctx.upload(T)
+        ps = ctx.patterns(spm.ALGO_MYERS, needles, k=ks)
+        assert ps.filterable, (it, [len(x) for x in needles], ks)
+        lo, hi, lc = 0, n, False
+        if it % 3 == 1:
+            lo = int(rng.integers(1, n // 2))
+            hi = int(rng.integers(lo + 1, n + 1))
+            lc = bool(it % 2)
+        hb = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=lc, max_hits=1 << 23).view()
+        hf = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=lc, max_hits=1 << 23)
+        assert hf.stats().fell_back == 0
+        assert np.array_equal(hf.view(), hb), (it, n, [len(x) for x in needles], ks, lo, hi, lc)
+        if it % 4 == 0 and not lc:
+            p = int(rng.integers(0, n_pat))
+            r = oracle.myers(T[lo:hi], needles[p], ks[p])
+            want = [(p, int(x) + lo, int(sc)) for x, sc in zip(r["pos"], r["score"])]
+            assert [h for h in _hits_list(hb) if h[0] == p] == want
+        text.close()
+        ps.close()
+
+
 def test_dna5_haystack_through_the_seed_filter(spm, ctx, oracle):
     """dna5 text (ranks A0 C1 G2 N3 T4) with runs of N and isolated Ns: the seed filter drops windows containing an
     N, verification runs on 5 Peq rows.  filter == brute == oracle.  Needles with an N are not filterable."""
