@@ -76,6 +76,25 @@ struct spm_hits
     void *d_aux[2] = {nullptr, nullptr}; // segmented scans: tile table, segment offsets (freed with the hits)
 };
 
+// scope guard for temporary device buffers: freed on every return path
+struct dev_scratch
+{
+    std::vector<void *> owned;
+    template <typename T>
+    hipError_t alloc(T **p, size_t bytes)
+    {
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+        if (e == hipSuccess)
+            owned.push_back(*p);
+        return e;
+    }
+    ~dev_scratch()
+    {
+        for (void *p : owned)
+            hipFree(p);
+    }
+};
+
 #define SPM_SET_ERR(ctx, ...)                                                                                          \
     do {                                                                                                               \
         char _b[512];                                                                                                  \

@@ -789,9 +789,21 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     const uint32_t H = J->H;
     const uint64_t nb = je - jb;
     hipStream_t st = ctx->stream;
-    hipEvent_t e0, e1;
-    SPM_HIP_CHECK(ctx, hipEventCreate(&e0));
-    SPM_HIP_CHECK(ctx, hipEventCreate(&e1));
+    dev_scratch tmp_bufs; // temporaries of the build, released on every return path
+    struct event_pair
+    {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~event_pair()
+        {
+            if (a)
+                hipEventDestroy(a);
+            if (b)
+                hipEventDestroy(b);
+        }
+    } ev;
+    SPM_HIP_CHECK(ctx, hipEventCreate(&ev.a));
+    SPM_HIP_CHECK(ctx, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     SPM_HIP_CHECK(ctx, hipEventRecord(e0, st));
 
     SPM_HIP_CHECK(ctx, hipMalloc(&J->d_alo, (n_blocks + 2) * 8));
@@ -806,14 +818,13 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
         const uint32_t chunk = 256;
         const uint64_t n_chunks = (n_blocks + chunk - 1) / chunk;
         int64_t *csum = nullptr;
-        SPM_HIP_CHECK(ctx, hipMalloc(&csum, n_chunks * H * 8));
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&csum, n_chunks * H * 8));
         const unsigned g = (unsigned)((n_chunks * H + 255) / 256);
         hipLaunchKernelGGL(jst_chunk_sum_kernel, dim3(g), dim3(256), 0, st, delta, n_blocks, H, chunk, csum);
         hipLaunchKernelGGL(jst_chunk_scan_kernel, dim3((H + 63) / 64), dim3(64), 0, st, csum, n_chunks, H);
         hipLaunchKernelGGL(jst_chunk_apply_kernel, dim3(g), dim3(256), 0, st, delta, n_blocks, H, chunk, csum);
         hipLaunchKernelGGL(jst_start_kernel, dim3((unsigned)(((n_blocks + 1) * H + 255) / 256)), dim3(256), 0, st, D);
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        hipFree(csum);
     }
     SPM_HIP_CHECK(ctx, hipGetLastError());
 
@@ -826,9 +837,9 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     unsigned long long *d_bytes = nullptr, *d_totals = nullptr;
     const uint64_t nbx = std::max<uint64_t>(nb, 1);
     SPM_HIP_CHECK(ctx, hipMalloc(&J->d_local_id, nbx * H * 2));
-    SPM_HIP_CHECK(ctx, hipMalloc(&d_nuniq, nbx * 4));
-    SPM_HIP_CHECK(ctx, hipMalloc(&d_bytes, nbx * 8));
-    SPM_HIP_CHECK(ctx, hipMalloc(&d_totals, 16));
+    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_nuniq, nbx * 4));
+    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_bytes, nbx * 8));
+    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_totals, 16));
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_totals, 0, 16, st));
     SPM_HIP_CHECK(ctx, hipMalloc(&J->d_ctx_base, (nb + 1) * 8));
     SPM_HIP_CHECK(ctx, hipMalloc(&J->d_byte_base, (nb + 1) * 8));
@@ -841,16 +852,16 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
         SPM_HIP_CHECK(ctx, hipGetLastError());
         // exclusive scans: contexts and bytes per block
         uint64_t *d_n64 = nullptr;
-        SPM_HIP_CHECK(ctx, hipMalloc(&d_n64, (nb + 1) * 8));
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_n64, (nb + 1) * 8));
         SPM_HIP_CHECK(ctx, hipMemsetAsync(d_n64, 0, (nb + 1) * 8, st));
         hipLaunchKernelGGL(jst_widen_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_nuniq, nb, d_n64);
         void *tmp = nullptr;
         size_t tmp_bytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_n64, J->d_ctx_base, (int)(nb + 1), st);
-        SPM_HIP_CHECK(ctx, hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
         hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_n64, J->d_ctx_base, (int)(nb + 1), st);
         uint64_t *d_b64 = nullptr;
-        SPM_HIP_CHECK(ctx, hipMalloc(&d_b64, (nb + 1) * 8));
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_b64, (nb + 1) * 8));
         SPM_HIP_CHECK(ctx, hipMemsetAsync(d_b64, 0, (nb + 1) * 8, st));
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_b64, d_bytes, nb * 8, hipMemcpyDeviceToDevice, st));
         hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_b64, J->d_byte_base, (int)(nb + 1), st);
@@ -858,13 +869,7 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx_bytes, J->d_byte_base + nb, 8, hipMemcpyDeviceToHost, st));
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, st));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        hipFree(tmp);
-        hipFree(d_n64);
-        hipFree(d_b64);
     }
-    hipFree(d_nuniq);
-    hipFree(d_bytes);
-    hipFree(d_totals);
     J->n_ctx = n_ctx;
     J->ctx_bytes = ctx_bytes;
     SPM_HIP_CHECK(ctx, hipMalloc(&J->d_ctx_off, (n_ctx + 1) * 8));
@@ -885,8 +890,6 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     SPM_HIP_CHECK(ctx, hipEventSynchronize(e1));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     J->stats = spm_jst_stats{};
     J->stats.haplotype_symbols = totals[1];
     J->stats.context_symbols = ctx_bytes;
