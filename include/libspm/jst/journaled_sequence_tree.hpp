@@ -278,7 +278,7 @@ public:
     // Search a compiled needle set over every haplotype.  `window` = max spm::window_size of the set, `needle_len`
     // = per-needle lengths (exact matchers report the begin position, so the last symbol is begin + |P| - 1).
     // The contexts are cut, deduplicated and spelled out on the device (spm_hip_jst_*, include/spm_hip.h); trees the
-    // device path does not take (alleles overlapping on a shared haplotype, > 1024 haplotypes) go through
+    // device path does not take (alleles overlapping on a shared haplotype, > 65 535 haplotypes) go through
     // search_host, which builds the same contexts on the host.  Both return the same hits.
     std::vector<jst_hit> search(spm_patterns * needles, std::size_t window, std::vector<std::uint32_t> const & needle_len,
                                 bool reports_begin, std::size_t block = 0, jst_search_stats * stats = nullptr) const

@@ -185,7 +185,8 @@ void spm_hip_hits_destroy(spm_hits *hits);
  * Alleles: sorted by `pos` (ties keep the given order); allele i replaces reference[pos, pos + ref_len) by
  * alt_pool[alt_off, alt_off + alt_len).  coverage: n_alleles x ceil(n_haplotypes / 64) words, bit h of row i set iff
  * haplotype h carries allele i.  Two alleles that overlap on the reference (pos_j < pos_i + ref_len_i for i < j) must
- * have disjoint coverage (multi-allelic sites); otherwise SPM_E_UNSUPPORTED.  At most 1024 haplotypes. */
+ * have disjoint coverage (multi-allelic sites); otherwise SPM_E_UNSUPPORTED.  At most 65 535 haplotypes; contexts are
+ * shared among the haplotypes of one group of 1024. */
 typedef struct spm_jst_allele {
     uint64_t pos;
     uint32_t ref_len;

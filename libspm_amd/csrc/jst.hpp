@@ -12,7 +12,7 @@
 //   3. a context = the symbols a (block, haplotype) pair owns plus window-1 symbols of left context.  Its signature is
 //      exact: where the left context starts (reference position, or allele + offset inside an alt), its length, and
 //      the bit set of the alleles the haplotype carries over that stretch.  Equal signatures <=> byte-identical
-//      contexts, so one workgroup per block groups its haplotypes by signature in LDS;
+//      contexts, so one workgroup per (block, group of <= 1024 haplotypes) groups them by signature in LDS;
 //   4. one representative per group is spelled out into the context buffer (wave-cooperative copies of reference
 //      runs and alt runs), the buffer is scanned as independent segments by the ordinary engines, and each hit whose
 //      last symbol lies in the owned part is fanned out to the haplotypes of its group.
@@ -28,7 +28,9 @@ static_assert(sizeof(spm_jst_allele) == 24 && sizeof(spm_jst_hit) == 24 && sizeo
 namespace spm_hip
 {
 
-constexpr uint32_t kJstMaxHap = 1024;   // haplotypes per tree on the device path (signature table lives in LDS)
+constexpr uint32_t kJstGroup = 1024;    // haplotypes whose contexts are compared with each other (signature table in LDS);
+                                        // larger trees are cut into groups of this size, contexts are shared within a group
+constexpr uint32_t kJstMaxHap = 65535;  // haplotype indices are reported as uint32, group-local ids are 15 bits
 constexpr uint32_t kJstMaskWords = 8;   // 256 alleles per context signature; denser stretches are not shared
 constexpr uint32_t kJstSigWords = 4 + kJstMaskWords;
 constexpr uint16_t kJstNone = 0xFFFF;   // (block, haplotype) owns no symbol
@@ -44,6 +46,7 @@ struct jst_dev
     const uint64_t *cov;
     uint64_t n_alleles;
     uint32_t cw, n_hap, max_rlen, window;
+    uint32_t n_groups;    // ceil(n_hap / kJstGroup)
     uint64_t L, n_blocks; // all blocks of the reference
     uint64_t jb, je;      // indexed blocks
     const uint64_t *a_lo; // [n_blocks + 1]: first allele with pos >= j * L
@@ -264,7 +267,10 @@ struct jst_index_out
 __global__ __launch_bounds__(256) void jst_dedupe_kernel(jst_dev J, jst_index_out O)
 {
     extern __shared__ uint32_t lds[];
-    const uint32_t H = J.n_hap;
+    // this workgroup: block jr of the indexed range, haplotypes [h0, h0 + H)
+    const uint64_t jr = blockIdx.x / J.n_groups;
+    const uint32_t h0 = (uint32_t)(blockIdx.x % J.n_groups) * kJstGroup;
+    const uint32_t H = min(kJstGroup, J.n_hap - h0);
     uint32_t n_slots = 64;
     while (n_slots < 2 * H)
         n_slots <<= 1;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void jst_dedupe_kernel(jst_dev J, jst_index_ou
     uint32_t *slot_of = uid + n_slots;         // [H]
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_bytes, s_ctx, s_owned;
-    const uint64_t j = J.jb + blockIdx.x;
+    const uint64_t j = J.jb + jr;
     if (threadIdx.x == 0) {
         s_n = 0;
         s_bytes = 0;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void jst_dedupe_kernel(jst_dev J, jst_index_ou
     __syncthreads();
     for (uint32_t h = threadIdx.x; h < H; h += blockDim.x) {
         jst_walk W;
-        jst_left_walk(J, j, h, W);
+        jst_left_walk(J, j, h0 + h, W);
         for (uint32_t w = 0; w < kJstSigWords; ++w)
             sig[h * kJstSigWords + w] = W.sig[w];
         slot_of[h] = W.empty ? 0xFFFFFFFFu : 0;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256) void jst_dedupe_kernel(jst_dev J, jst_index_ou
         uint16_t v = kJstNone;
         if (s != 0xFFFFFFFFu)
             v = (uint16_t)(uid[s] | (slots[s] == h ? 0x8000u : 0u));
-        O.local_id[(uint64_t)blockIdx.x * H + h] = v;
+        O.local_id[jr * J.n_hap + h0 + h] = v;
     }
     if (threadIdx.x == 0) {
         O.n_uniq[blockIdx.x] = s_n;
@@ -360,26 +366,28 @@ struct jst_emit_out
 __global__ __launch_bounds__(256) void jst_emit_kernel(jst_dev J, jst_emit_out O)
 {
     extern __shared__ uint32_t lds[];
-    const uint32_t H = J.n_hap;
+    const uint64_t cb = blockIdx.x; // (block, haplotype group) cell
+    const uint64_t jr = cb / J.n_groups, j = J.jb + jr;
+    const uint32_t h0 = (uint32_t)(cb % J.n_groups) * kJstGroup;
+    const uint32_t H = min(kJstGroup, J.n_hap - h0);
     uint32_t *rep = lds;        // [n_uniq] representative haplotype of group id
-    uint32_t *len = rep + H;    // [n_uniq]
-    uint32_t *off = len + H;    // [n_uniq] byte offset inside the block's stretch (fits: <= H * (L + window + alts))
-    const uint64_t jr = blockIdx.x, j = J.jb + jr;
-    const uint32_t n_uniq = (uint32_t)(O.ctx_base[jr + 1] - O.ctx_base[jr]);
+    uint32_t *len = rep + kJstGroup;    // [n_uniq]
+    uint32_t *off = len + kJstGroup;    // [n_uniq] byte offset inside the cell's stretch (fits: <= H * (L + window + alts))
+    const uint32_t n_uniq = (uint32_t)(O.ctx_base[cb + 1] - O.ctx_base[cb]);
     if (n_uniq == 0)
         return;
     for (uint32_t h = threadIdx.x; h < H; h += blockDim.x) {
-        const uint16_t v = O.local_id[jr * H + h];
+        const uint16_t v = O.local_id[jr * J.n_hap + h0 + h];
         if (v != kJstNone && (v & 0x8000u))
-            rep[v & 0x7FFFu] = h;
+            rep[v & 0x7FFFu] = h0 + h;
     }
     __syncthreads();
     for (uint32_t u = threadIdx.x; u < n_uniq; u += blockDim.x) {
         jst_walk W;
         jst_left_walk(J, j, rep[u], W);
         len[u] = W.len;
-        O.ctx_block[O.ctx_base[jr] + u] = (uint32_t)jr;
-        O.ctx_owned[O.ctx_base[jr] + u] = W.owned_from;
+        O.ctx_block[O.ctx_base[cb] + u] = (uint32_t)cb;
+        O.ctx_owned[O.ctx_base[cb] + u] = W.owned_from;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -391,13 +399,13 @@ __global__ __launch_bounds__(256) void jst_emit_kernel(jst_dev J, jst_emit_out O
     }
     __syncthreads();
     for (uint32_t u = threadIdx.x; u < n_uniq; u += blockDim.x)
-        O.ctx_off[O.ctx_base[jr] + u] = O.byte_base[jr] + off[u];
+        O.ctx_off[O.ctx_base[cb] + u] = O.byte_base[cb] + off[u];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     for (uint32_t u = wave; u < n_uniq; u += n_waves) {
         const uint32_t h = rep[u];
         jst_walk W; // wave-uniform: every lane walks the same haplotype
         jst_left_walk(J, j, h, W);
-        uint8_t *out = O.buffer + O.byte_base[jr] + off[u];
+        uint8_t *out = O.buffer + O.byte_base[cb] + off[u];
         uint64_t remaining = W.len;
         uint64_t i = W.next_allele, r = W.start_ref;
         bool in_alt = W.kind == 1;
@@ -460,7 +468,7 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
     bool live = t < F.n_hits;
     spm_hit hit{};
     uint64_t c = 0, local = 0, jr = 0;
-    uint32_t id = 0, members = 0;
+    uint32_t id = 0, members = 0, h_lo = 0, h_hi = 0;
     if (live) {
         hit = F.hits[t];
         const uint64_t probe = F.report_begin ? hit.pos : hit.pos - 1; // a symbol of the hit's own context
@@ -478,9 +486,12 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
         live = last >= F.ctx_owned[c];
     }
     if (live) {
-        jr = F.ctx_block[c];
-        id = (uint32_t)(c - F.ctx_base[jr]);
-        for (uint32_t h = 0; h < J.n_hap; ++h) {
+        const uint64_t cb = F.ctx_block[c]; // (block, haplotype group) cell of the context
+        jr = cb / J.n_groups;
+        h_lo = (uint32_t)(cb % J.n_groups) * kJstGroup;
+        h_hi = min(J.n_hap, h_lo + kJstGroup);
+        id = (uint32_t)(c - F.ctx_base[cb]);
+        for (uint32_t h = h_lo; h < h_hi; ++h) {
             const uint16_t v = F.local_id[jr * J.n_hap + h];
             members += (v != kJstNone && (uint32_t)(v & 0x7FFFu) == id) ? 1u : 0u;
         }
@@ -502,7 +513,7 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
     // pass 2: report the hit for every haplotype of the group, in haplotype coordinates
     unsigned long long slot = base + (incl - members);
     const uint64_t j = J.jb + jr;
-    for (uint32_t h = 0; h < J.n_hap; ++h) {
+    for (uint32_t h = h_lo; h < h_hi; ++h) {
         const uint16_t v = F.local_id[jr * J.n_hap + h];
         if (v == kJstNone || (uint32_t)(v & 0x7FFFu) != id)
             continue;
@@ -568,6 +579,7 @@ struct spm_jst
         J.n_alleles = al.size();
         J.cw = cw;
         J.n_hap = H;
+        J.n_groups = (H + spm_hip::kJstGroup - 1) / spm_hip::kJstGroup;
         J.max_rlen = max_rlen;
         J.window = window;
         J.L = L;
@@ -617,8 +629,7 @@ extern "C" int spm_hip_jst_create(spm_ctx *ctx, const spm_text *reference, const
         return SPM_E_INVALID;
     }
     if (n_haplotypes > spm_hip::kJstMaxHap) {
-        SPM_SET_ERR(ctx, "spm_hip_jst_create: %u haplotypes, the device path holds at most %u", n_haplotypes,
-                    spm_hip::kJstMaxHap);
+        SPM_SET_ERR(ctx, "spm_hip_jst_create: %u haplotypes, at most %u", n_haplotypes, spm_hip::kJstMaxHap);
         return SPM_E_UNSUPPORTED;
     }
     const uint32_t cw = (n_haplotypes + 63) / 64;
@@ -828,45 +839,52 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     }
     SPM_HIP_CHECK(ctx, hipGetLastError());
 
-    // group the haplotypes of every block by context signature
+    // group the haplotypes of every (block, haplotype group) cell by context signature
+    const uint32_t Hg = std::min<uint32_t>(H, kJstGroup); // haplotypes a workgroup compares
+    const uint64_t n_groups = D.n_groups;
+    const uint64_t nc = nb * n_groups;                    // cells
+    if (nc >= (1ull << 31)) {
+        SPM_SET_ERR(ctx, "spm_hip_jst_index: too many (block, haplotype group) cells");
+        return SPM_E_UNSUPPORTED;
+    }
     uint32_t n_slots = 64;
-    while (n_slots < 2 * H)
+    while (n_slots < 2 * Hg)
         n_slots <<= 1;
-    const size_t lds_dedupe = ((size_t)H * kJstSigWords + 2 * n_slots + H) * 4;
+    const size_t lds_dedupe = ((size_t)Hg * kJstSigWords + 2 * n_slots + Hg) * 4;
     uint32_t *d_nuniq = nullptr;
     unsigned long long *d_bytes = nullptr, *d_totals = nullptr;
-    const uint64_t nbx = std::max<uint64_t>(nb, 1);
-    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_local_id, nbx * H * 2));
-    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_nuniq, nbx * 4));
-    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_bytes, nbx * 8));
+    const uint64_t ncx = std::max<uint64_t>(nc, 1);
+    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_local_id, std::max<uint64_t>(nb, 1) * H * 2));
+    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_nuniq, ncx * 4));
+    SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_bytes, ncx * 8));
     SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_totals, 16));
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_totals, 0, 16, st));
-    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_ctx_base, (nb + 1) * 8));
-    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_byte_base, (nb + 1) * 8));
+    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_ctx_base, (nc + 1) * 8));
+    SPM_HIP_CHECK(ctx, hipMalloc(&J->d_byte_base, (nc + 1) * 8));
     unsigned long long totals[2] = {0, 0};
     uint64_t n_ctx = 0, ctx_bytes = 0;
-    if (nb) {
+    if (nc) {
         jst_index_out O{J->d_local_id, d_nuniq, d_bytes, d_totals};
         hipFuncSetAttribute((const void *)jst_dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dedupe);
-        hipLaunchKernelGGL(jst_dedupe_kernel, dim3((unsigned)nb), dim3(256), lds_dedupe, st, D, O);
+        hipLaunchKernelGGL(jst_dedupe_kernel, dim3((unsigned)nc), dim3(256), lds_dedupe, st, D, O);
         SPM_HIP_CHECK(ctx, hipGetLastError());
-        // exclusive scans: contexts and bytes per block
+        // exclusive scans: contexts and bytes per cell
         uint64_t *d_n64 = nullptr;
-        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_n64, (nb + 1) * 8));
-        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_n64, 0, (nb + 1) * 8, st));
-        hipLaunchKernelGGL(jst_widen_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_nuniq, nb, d_n64);
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_n64, (nc + 1) * 8));
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_n64, 0, (nc + 1) * 8, st));
+        hipLaunchKernelGGL(jst_widen_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, d_nuniq, nc, d_n64);
         void *tmp = nullptr;
         size_t tmp_bytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_n64, J->d_ctx_base, (int)(nb + 1), st);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_n64, J->d_ctx_base, (int)(nc + 1), st);
         SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_n64, J->d_ctx_base, (int)(nb + 1), st);
+        hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_n64, J->d_ctx_base, (int)(nc + 1), st);
         uint64_t *d_b64 = nullptr;
-        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_b64, (nb + 1) * 8));
-        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_b64, 0, (nb + 1) * 8, st));
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_b64, d_bytes, nb * 8, hipMemcpyDeviceToDevice, st));
-        hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_b64, J->d_byte_base, (int)(nb + 1), st);
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(&n_ctx, J->d_ctx_base + nb, 8, hipMemcpyDeviceToHost, st));
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx_bytes, J->d_byte_base + nb, 8, hipMemcpyDeviceToHost, st));
+        SPM_HIP_CHECK(ctx, tmp_bufs.alloc(&d_b64, (nc + 1) * 8));
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_b64, 0, (nc + 1) * 8, st));
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_b64, d_bytes, nc * 8, hipMemcpyDeviceToDevice, st));
+        hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_b64, J->d_byte_base, (int)(nc + 1), st);
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(&n_ctx, J->d_ctx_base + nc, 8, hipMemcpyDeviceToHost, st));
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx_bytes, J->d_byte_base + nc, 8, hipMemcpyDeviceToHost, st));
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, st));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
@@ -882,8 +900,8 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     if (n_ctx) {
         jst_emit_out E{J->d_local_id, J->d_ctx_base, J->d_byte_base, J->d_ctx_off, J->d_ctx_block, J->d_ctx_owned,
                        J->ctx_text->d};
-        const size_t lds_emit = (size_t)H * 3 * 4;
-        hipLaunchKernelGGL(jst_emit_kernel, dim3((unsigned)nb), dim3(256), lds_emit, st, D, E);
+        const size_t lds_emit = (size_t)kJstGroup * 3 * 4;
+        hipLaunchKernelGGL(jst_emit_kernel, dim3((unsigned)nc), dim3(256), lds_emit, st, D, E);
         SPM_HIP_CHECK(ctx, hipGetLastError());
     }
     SPM_HIP_CHECK(ctx, hipEventRecord(e1, st));

@@ -105,6 +105,7 @@ def _got(rec):
     (30_000, 64, 80, 300, "myers", 50, 2, 256),       # deletions / insertions longer than a block
     (40_000, 7, 1500, 3, "shiftor", 24, 0, 128),      # dense variants, exact matcher (begin positions)
     (50_000, 33, 200, 20, "myers", 200, 8, 0),        # default block length
+    (12_000, 1500, 60, 8, "myers", 32, 1, 256),       # two haplotype groups (contexts shared within groups of 1024)
 ])
 def test_device_jst_equals_per_haplotype_scans(spm, ctx, oracle, cfg):
     n_ref, n_hap, n_var, max_len, algo_name, L, k, block = cfg
