@@ -1224,6 +1224,10 @@ int run_filter(const scan_args &A)
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
     const uint64_t n_chunks = (P.hi - (P.lo & ~1023ull) + 1023) / 1024;
     uint64_t span = n_chunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 32))) + 1;
+    // small texts: at least 64 KiB per dequeue as long as every wave still gets ~4 spans (a 1 GiB text ran 14 % faster
+    // with 64-chunk spans than with the 24 the rule above gives: fewer dequeue rounds, each a workgroup barrier)
+    if (span < 64)
+        span = std::max<uint64_t>(span, std::min<uint64_t>(64, n_chunks / (n_waves * 4) + 1));
     span = std::min<uint64_t>(std::max<uint64_t>(span, 8), 4096);
     const int fs = env_int("SPM_HIP_FILTER_SPAN", 0);
     if (fs > 0)
