@@ -59,7 +59,7 @@ def test_reference_golden_vectors(spm, ctx, oracle):
                 assert [g[1] for g in got] == case["scores"], (case["name"], engine)
 
 
-@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 300, 1024])
+@pytest.mark.parametrize("m", [1, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 300, 1024, 2047, 2048])
 @pytest.mark.parametrize("k", [0, 1, 3])
 def test_myers_brute_block_borders(spm, ctx, oracle, m, k):
     """|P| around every word border, needles of mixed length in one set, planted occurrences with edits."""
