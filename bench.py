@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 SEED_TEXT = 0x5EED0001
 SEED_PAT = 0x5EED0002
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+HBM_STREAM_PROBE_GBS = 7030.0  # best pure streaming read of a 16 GiB buffer on this GPU model (tools/hbm_read_probe,
+#                                profiles/r01/hbm_read_probe_16GiB.log); reported beside `frac`, never instead of it
 
 WORKLOADS = {
     # name: (algo, |P|, kmax, needles, text GiB per GPU, description)
@@ -449,6 +451,8 @@ def main():
                     "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_brute_kernel",
                     "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": hi - lo,
+                    "stream_read_probe": HBM_STREAM_PROBE_GBS,
+                    "frac_of_stream_read_probe": achieved / HBM_STREAM_PROBE_GBS,
                 },
                 "hits": int(len(hits)),
                 "needles_found": int(len(found)),
