@@ -12,8 +12,8 @@ ctx = S.Context(0)
 n = int(float(sys.argv[1]) * 2**30) if len(sys.argv) > 1 else 3 << 29
 text = ctx.generate(0x5EED0001, 0, n)
 needles = [S.synth_pattern(0x5EED0001, 0x5EED0002, n, p, 1024, 64)[0] for p in range(256)]
-for env in ({}, {"SPM_HIP_VERIFY_WAVE_MIN_WORDS": "0"}, {"SPM_HIP_FILTER_MERGE": "0"}, {"SPM_HIP_FILTER_DYN": "0"},
-            {"SPM_HIP_FILTER_KEYLEN": "15"}):
+for env in ({}, {"SPM_HIP_FILTER_QUEUE": "0"}, {"SPM_HIP_FILTER_KEYLEN": "15"}, {"SPM_HIP_FILTER_KEYLEN": "13"},
+            {"SPM_HIP_FILTER_THREADS": "256"}, {"SPM_HIP_FILTER_SPANS_PER_WAVE": "8"}):
     os.environ.update(env)
     ps = ctx.patterns(S.ALGO_MYERS, needles, k=64)
     best = None
