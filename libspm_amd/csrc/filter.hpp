@@ -527,8 +527,10 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
 // (U KiB contiguous per wave) while the unconditional 16-byte loads of the next group are already in flight, so
 // each wave keeps 2*U KiB outstanding.  Only groups that lie fully inside the text take this path; the ragged end
 // of the text goes through a guarded one-chunk loop (bytes past the end read as 0).
+// 512 threads: 8 waves per CU is the measured best for the HBM-bound 1-byte text, and a bound of 1024 leaves 128 VGPRs,
+// which made the masked-key stride-2 variant spill to scratch inside the streaming loop (+31 % kernel time).
 template <int S, int U, bool NT, int HV, int SIG, bool KM>
-__global__ __launch_bounds__(1024) void seed_filter_kernel(const filter_params P)
+__global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
     // ---- stage the level-1 table in LDS (once per workgroup; the grid is persistent) ----

@@ -1206,8 +1206,8 @@ int run_filter(const scan_args &A)
     const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
                             !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
     // measured best: 8 waves per CU on the 1-byte text (HBM-bound), 16 on the 2-bit shadow (LDS/VALU-bound)
-    const uint32_t threads =
-        (uint32_t)std::max(64, std::min(1024, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
+    const uint32_t threads = (uint32_t)std::max(
+        64, std::min(use_packed ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one candidate-chunk record (4 words) per wave
     size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * 16;
     // strides 1 and 2: survivors are queued in LDS and resolved 64 at a time, if the queues fit beside the table
@@ -1242,7 +1242,7 @@ int run_filter(const scan_args &A)
     const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
     const bool NT = env_int("SPM_HIP_FILTER_NT", 1) != 0;
     P.hash_variant = F.hash_variant;
-    const bool short_keys = F.key_len < 16;
+    const bool short_keys = F.key_len < 16 || env_int("SPM_HIP_FILTER_FORCE_MASKED", 0) != 0; // (the env: diagnostics)
 #define LAUNCH_FILTER4(S, UU, NTT, HV, SG, KM)                                                                         \
     do {                                                                                                               \
         hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV, SG, KM>,                                  \
