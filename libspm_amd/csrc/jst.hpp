@@ -192,10 +192,15 @@ __device__ inline void jst_left_walk(const jst_dev &J, uint64_t j, uint32_t h, j
     bool overflow = false;
     auto set_bit = [&](uint64_t idx) {
         const uint64_t t = a_hi - 1 - idx;
-        if (t >= 32ull * kJstMaskWords)
+        if (t >= 32ull * kJstMaskWords) {
             overflow = true;
-        else
-            W.sig[4 + (t >> 5)] |= 1u << (t & 31);
+        } else {
+            const uint32_t bit = 1u << (t & 31);
+#pragma unroll
+            for (uint32_t w = 0; w < kJstMaskWords; ++w) // static indices: the signature stays in registers
+                if ((uint32_t)(t >> 5) == w)
+                    W.sig[4 + w] |= bit;
+        }
     };
     for (uint64_t i = J.a_lo[j]; i < a_hi; ++i)
         if (jst_carried(J, i, h))
