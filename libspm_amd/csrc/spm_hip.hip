@@ -145,59 +145,76 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
     const int force_s = env_int("SPM_HIP_FILTER_STRIDE", 0);
     if (force_s > 0 && (uint32_t)force_s <= Smax)
         Smax = (uint32_t)force_s;
-    // keys per pass: the fingerprint table has 65536 slots and is built at <= 75 % load
-    const uint64_t cap = (uint64_t)std::max(1024, env_int("SPM_HIP_FILTER_MAX_KEYS", 49152));
-    // stride: the largest one when a single pass suffices; otherwise the one minimising passes x cost per pass
-    // (a pass with stride S looks at 16/S windows per 16 symbols; measured cost grows ~0.3x per doubling)
-    uint32_t S = Smax;
-    if (n_seeds * Smax > cap && force_s <= 0) {
-        double best = 1e300;
-        for (uint32_t s = Smax; s >= 1; s >>= 1) {
-            const double passes = (double)((n_seeds * s + cap - 1) / cap);
-            const double cost = passes * (1.0 + 0.3 * ((double)Smax / s - 1.0));
-            if (cost < best) {
-                best = cost;
-                S = s;
+    // keys per pass: the fingerprint table has 65536 slots; the hash-and-displace build succeeds up to ~88 % load
+    // (57 344 keys: C4's 400 000 keys take 7 passes instead of the 9 of a 75 % table).  If a dense batch cannot be
+    // placed, the whole set is re-partitioned with smaller batches rather than dropping to the Bloom cascade.
+    const uint64_t cap0 = (uint64_t)std::max(1024, env_int("SPM_HIP_FILTER_MAX_KEYS", 57344));
+    const bool want_chd = env_int("SPM_HIP_FILTER_HASH", 2) == 2;
+    const uint64_t caps[3] = {cap0, cap0 * 7 / 8, cap0 * 3 / 4};
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const uint64_t cap = caps[attempt];
+        bool dense_failure = false;
+        // stride: the largest one when a single pass suffices; otherwise the one minimising passes x cost per pass
+        // (a pass with stride S looks at 16/S windows per 16 symbols; measured cost grows ~0.3x per doubling)
+        uint32_t S = Smax;
+        if (n_seeds * Smax > cap && force_s <= 0) {
+            double best = 1e300;
+            for (uint32_t s = Smax; s >= 1; s >>= 1) {
+                const double passes = (double)((n_seeds * s + cap - 1) / cap);
+                const double cost = passes * (1.0 + 0.3 * ((double)Smax / s - 1.0));
+                if (cost < best) {
+                    best = cost;
+                    S = s;
+                }
             }
         }
-    }
-    const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
-    ps->filter_stride = S;
-    ps->filter_key_len = H;
-    uint32_t p0 = 0;
-    while (p0 < ps->n) {
-        uint64_t keys = 0;
-        uint32_t p1 = p0;
-        while (p1 < ps->n) {
-            const uint64_t add = (uint64_t)plan_seeds((uint32_t)ps->m[p1], ps->is_myers() ? (uint32_t)ps->k[p1] : 0).n * S;
-            if (keys + add > cap && p1 > p0)
-                break;
-            keys += add;
-            ++p1;
-        }
-        if (ps->fidx.size() >= max_passes) {
-            for (filter_index &F : ps->fidx) {
-                hipFree(F.d_bitmap);
-                hipFree(F.d_ht);
+        const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
+        ps->filter_stride = S;
+        ps->filter_key_len = H;
+        uint32_t p0 = 0;
+        while (p0 < ps->n) {
+            uint64_t keys = 0;
+            uint32_t p1 = p0;
+            while (p1 < ps->n) {
+                const uint64_t add = (uint64_t)plan_seeds((uint32_t)ps->m[p1], ps->is_myers() ? (uint32_t)ps->k[p1] : 0).n * S;
+                if (keys + add > cap && p1 > p0)
+                    break;
+                keys += add;
+                ++p1;
             }
-            ps->fidx.clear();
-            return SPM_OK; // too many passes to be worth it: brute force
-        }
-        filter_index F;
-        F.key_len = H;
-        int rc = build_one_index(ctx, ps, p0, p1, S, F);
-        if (rc != SPM_OK)
-            return rc;
-        if (!F.ok) {
-            for (filter_index &G : ps->fidx) {
-                hipFree(G.d_bitmap);
-                hipFree(G.d_ht);
+            if (ps->fidx.size() >= max_passes) {
+                for (filter_index &F : ps->fidx) {
+                    hipFree(F.d_bitmap);
+                    hipFree(F.d_ht);
+                }
+                ps->fidx.clear();
+                return SPM_OK; // too many passes to be worth it: brute force
             }
-            ps->fidx.clear();
+            filter_index F;
+            F.key_len = H;
+            int rc = build_one_index(ctx, ps, p0, p1, S, F);
+            if (rc != SPM_OK)
+                return rc;
+            if (!F.ok) {
+                for (filter_index &G : ps->fidx) {
+                    hipFree(G.d_bitmap);
+                    hipFree(G.d_ht);
+                }
+                ps->fidx.clear();
+                return SPM_OK;
+            }
+            ps->fidx.push_back(F);
+            p0 = p1;
+        }
+        for (const filter_index &F : ps->fidx)
+            dense_failure = dense_failure || (want_chd && F.hash_variant != 2);
+        if (!dense_failure || attempt == 2)
             return SPM_OK;
+        for (filter_index &F : ps->fidx) {
+            hipFree(F.d_bitmap);
+            hipFree(F.d_ht);
         }
-        ps->fidx.push_back(F);
-        p0 = p1;
+        ps->fidx.clear();
     }
     return SPM_OK;
 }
@@ -245,7 +262,7 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
         uint32_t n_slots = 1024;
         while (n_slots < 2 * uniq.size() && n_slots < 65536)
             n_slots <<= 1;
-        bool ok = uniq.size() <= (size_t)(0.8 * n_slots);
+        bool ok = uniq.size() <= (size_t)(0.96 * n_slots);
         const uint32_t n_buckets = std::max(64u, n_slots / 8);
         uint32_t lg = 0;
         while ((1u << lg) < n_buckets)

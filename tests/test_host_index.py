@@ -41,9 +41,15 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     big = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(6000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, big, 3)
     assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["stride"] == 2 and st["keys"] == 6000 * 4 * 2
-    # 20 000 needles: 80 000 seeds do not fit one table even at stride 1 -> two passes
+    # 20 000 needles: 80 000 seeds do not fit one table (57 344 keys) even at stride 1 -> sub-batches; the cost model
+    # prefers three passes at stride 2 to two at stride 1
     rc, st = _selftest(spm, spm.ALGO_MYERS, big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)], 3)
-    assert rc == 0 and st["missing"] == 0 and st["passes"] == 2 and st["stride"] == 1 and st["keys"] == 80000
+    assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (3, 2, 160000)
+    assert st["hash_variant"] == 2
+    # a C4-sized set: 400 000 seeds at stride 1 in 7 passes
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(100000)], 3)
+    assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (7, 1, 400000)
+    assert st["hash_variant"] == 2
     # mixed lengths and k: the stride follows the shortest seed
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
