@@ -93,7 +93,8 @@ typedef struct spm_scan_stats {
     uint64_t n_candidates;
     uint64_t n_hits;
     uint32_t main_launches;
-    uint32_t n_bands;     /* filter engine, needles with k >= 8: diagonal bands verified after candidate merging */
+    uint32_t n_bands;     /* filter engine: what was actually verified -- diagonal bands after candidate merging (sets with
+                             k >= 8), else the candidates whose whole seed matches the text */
 } spm_scan_stats;
 
 /* ---- context -------------------------------------------------------------------------------------- */

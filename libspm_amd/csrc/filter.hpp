@@ -39,6 +39,20 @@ namespace spm_hip
 
 constexpr uint32_t kKeyMax = 16; // symbols per key: 16 whenever the seeds allow it, down to kKeyMin for short seeds
 constexpr uint32_t kKeyMin = 12;
+
+// Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
+// needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
+// hits per diagonal band and skip bands with a single one (candidate merging below).
+constexpr uint32_t kMergeMinK = 8;
+struct seed_plan
+{
+    uint32_t n, q;
+};
+__host__ __device__ inline seed_plan plan_seeds(uint32_t m, uint32_t k)
+{
+    const uint32_t surplus = (k >= kMergeMinK && k <= 1000 && m / (k + 2) >= kKeyMin) ? 2u : 1u;
+    return {k + surplus, m / (k + surplus)};
+}
 constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
 
 struct candidate
@@ -812,6 +826,9 @@ struct verify_params
     uint32_t max_span;     // merged candidates: extra end positions a diagonal band answers for (0: none merged)
     uint32_t cand_counter; // index of the candidate count in `counters` (1: raw candidates, 3: merged bands)
     uint32_t wave_text;    // wave-per-candidate kernel: bytes of LDS per group for the candidate's text window
+    const uint8_t *needle_ranks;    // whole-seed check: the needles' symbols back to back (nullptr: check disabled)
+    const uint32_t *needle_offsets; // start of every needle in needle_ranks
+    uint32_t text_sigma;
     unsigned long long *seen; // hash set of (pattern << 40 | end)
     uint32_t seen_mask;
     spm_hit *hits;
@@ -823,6 +840,32 @@ struct verify_params
     const uint32_t *seg_owned;    // optional, per segment: only hits whose last symbol lies at or behind this offset
                                   // are wanted (journaled-sequence contexts: the symbols before it are left context)
 };
+
+// A candidate says: the key window at needle offset x matches the text at t.  The pigeonhole argument needs a seed that
+// occurs in the text UNCHANGED, and such a seed yields a candidate of its own -- so a candidate whose whole seed does
+// not match exactly can be dropped without losing an occurrence.  On long texts most candidates are chance matches of
+// the 16-symbol key (C4: 800 000 of 1 140 000; C3: 16 000 of 20 000); they fail this check after ~1.3 symbols.
+__device__ __forceinline__ bool seed_intact(const verify_params &P, const candidate &c, int64_t hay_b, int64_t hay_e)
+{
+    if (!P.needle_ranks)
+        return true;
+    const uint32_t pat = c.val >> 11, x = c.val & 0x7FF;
+    const seed_plan sp = plan_seeds((uint32_t)P.m[pat], (uint32_t)P.k[pat]);
+    const uint32_t o = (x / sp.q) * sp.q; // start of the seed inside the needle
+    const int64_t ts = (int64_t)c.t - (int64_t)(x - o); // where the seed would start in the text
+    if (ts < hay_b || ts + (int64_t)sp.q > hay_e)
+        return false; // it would stick out of the haystack
+    const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat] + o;
+    const uint8_t *tx = P.text + ts;
+    const uint32_t w0 = x - o, w1 = w0 + P.key_len; // the key window itself already matched
+    for (uint32_t i = 0; i < sp.q; ++i) {
+        if (i >= w0 && i < w1)
+            continue;
+        if (tx[i] != nd[i])
+            return false;
+    }
+    return true;
+}
 
 // One lane per candidate.  Same recurrence and layout as the brute kernel (32-bit words, v_bitop3, needles
 // top-aligned so that the score delta is bit 31 of the top word): the candidate's needle rows are staged from the
@@ -883,6 +926,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
             own_e = se;
             hay_b = sb;
         }
+        if (!merged && !seed_intact(P, c, hay_b, own_e))
+            continue;
         if (e_lo < own_b + 1)
             e_lo = own_b + 1;
         if (e_hi > own_e)
@@ -1050,6 +1095,8 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 own_e = se;
                 hay_b = sb;
             }
+            if (!merged && !seed_intact(P, c, hay_b, own_e))
+                active = false;
             if (e_lo < own_b + 1)
                 e_lo = own_b + 1;
             if (e_hi > own_e)
@@ -1177,6 +1224,64 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         wave_count_add(P.hit_counter + 5, n_valid);
 }
 
+// ---- candidate compaction (needles with few errors) ----------------------------------------------------------------
+// One lane per candidate means a wave is as slow as its slowest lane, so dropping chance candidates inside the
+// verification kernel buys nothing while every wave still holds a true one.  This pass applies the whole-seed check
+// first and hands the verification a dense list of the survivors.
+__global__ void compact_candidates_kernel(const verify_params P, candidate *out, unsigned long long *out_count,
+                                          uint64_t out_cap)
+{
+    unsigned long long n = P.counters[1];
+    if (n > P.cand_cap)
+        n = P.cand_cap;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t n_valid = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride; // wave-uniform trip count: the appends are wave-collective
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool keep = false;
+        candidate c;
+        c.t = 0;
+        c.val = kCandInvalid;
+        c.pad = 0;
+        if (i < n) {
+            c = P.cand[i];
+            keep = c.val != kCandInvalid;
+            n_valid += keep ? 1u : 0u;
+        }
+        if (keep) {
+            int64_t hay_b = (int64_t)P.ctx_begin, hay_e = (int64_t)P.scan_end;
+            if (P.seg_offsets) {
+                uint64_t lo = 0, hi = P.n_segments;
+                while (hi - lo > 1) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (P.seg_offsets[mid] <= c.t)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                hay_b = (int64_t)P.seg_offsets[lo];
+                hay_e = (int64_t)P.seg_offsets[lo + 1];
+                keep = (int64_t)c.t + (int64_t)P.key_len <= hay_e;
+            }
+            keep = keep && seed_intact(P, c, hay_b, hay_e);
+        }
+        const uint64_t m = __ballot(keep);
+        if (m != 0) {
+            unsigned long long base = 0;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            if ((int)lane == leader)
+                base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader);
+            const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
+            if (keep && idx < out_cap)
+                out[idx] = c;
+        }
+    }
+    wave_count_add(P.hit_counter + 5, n_valid);
+}
+
 // ---- candidate merging for large k ------------------------------------------------------------------------------
 // With k+1 seeds every occurrence is verified once per surviving seed (65 times for k = 64) and short keys let chance
 // matches through.  Needles with k >= kMergeMinK therefore carry k+2 seeds: an occurrence with <= k errors keeps >= 2 of
@@ -1201,6 +1306,7 @@ struct merge_params
     uint32_t *count; // seed hits per band
     uint2 *own_slot; // per candidate: the table slots it claimed (primary, secondary band), 0xFFFFFFFF = none
     const uint32_t *seg_owned; // optional (verify_params::seg_owned): bands that end before it are not verified
+    verify_params V;           // text, needles, scan range: the whole-seed check of every candidate
     candidate *out;
     uint64_t out_cap;
 };
@@ -1229,6 +1335,10 @@ __global__ void merge_aux_kernel(const merge_params P)
             seg = lo;
             sb = (int64_t)P.seg_offsets[lo];
             drop = drop || (int64_t)c.t + (int64_t)P.key_len > (int64_t)P.seg_offsets[lo + 1];
+            if (!drop)
+                drop = !seed_intact(P.V, c, sb, (int64_t)P.seg_offsets[lo + 1]);
+        } else if (!drop) {
+            drop = !seed_intact(P.V, c, (int64_t)P.V.ctx_begin, (int64_t)P.V.scan_end);
         }
         // diagonal relative to the haystack, shifted so that it is never negative (t >= sb, offset <= max_m)
         const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;

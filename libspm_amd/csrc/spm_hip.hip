@@ -73,6 +73,8 @@ struct spm_patterns
     std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
     mutable uint64_t cand_hint = 0; // most candidates a filter scan of this set has produced so far
     uint8_t *d_surplus = nullptr;   // per needle: seeds - k (candidate merging); nullptr = no needle has k >= kMergeMinK
+    uint8_t *d_ranks = nullptr;     // filterable sets: the needles' symbols, back to back (whole-seed check of a candidate)
+    uint32_t *d_offsets = nullptr;  // ... and where each needle starts
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
 };
@@ -97,17 +99,6 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
 // Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
 // needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
 // hits per diagonal band and skip bands with a single one (filter.hpp, candidate merging).
-constexpr uint32_t kMergeMinK = 8;
-struct seed_plan
-{
-    uint32_t n, q;
-};
-static inline seed_plan plan_seeds(uint32_t m, uint32_t k)
-{
-    const uint32_t surplus = (k >= kMergeMinK && k <= 1000 && m / (k + 2) >= kKeyMin) ? 2u : 1u;
-    return {k + surplus, m / (k + surplus)};
-}
-
 // Seed filter applicability + partition of the needle set into sub-batches whose keys fit one LDS table.
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
@@ -497,6 +488,15 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         int rc = build_filter_index(ctx, ps.get());
         if (rc != SPM_OK)
             return rc;
+        if (!ps->fidx.empty()) {
+            const size_t nr = std::max<size_t>(ps->ranks.size(), 1);
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_ranks, nr));
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_offsets, ps->offsets.size() * sizeof(uint32_t)));
+            if (!ps->ranks.empty())
+                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t),
+                                         hipMemcpyHostToDevice));
+        }
         if (!ps->fidx.empty() && ps->max_k >= kMergeMinK && ps->max_k <= 1000) {
             std::vector<uint8_t> surplus(ps->m.size(), 1);
             for (uint32_t p = 0; p < ps->n; ++p)
@@ -520,6 +520,8 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_m);
     hipFree(p->d_k);
     hipFree(p->d_surplus);
+    hipFree(p->d_ranks);
+    hipFree(p->d_offsets);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
@@ -1175,7 +1177,7 @@ int run_filter(const scan_args &A)
     uint64_t band_slots = 1u << 12;
     while (merging && band_slots < 4 * cand_cap)
         band_slots <<= 1;
-    const size_t merged_bytes = merging ? 2 * cand_bytes : 0;
+    const size_t merged_bytes = 2 * cand_bytes; // merged bands, or the compacted candidate list
     const size_t aux_bytes = merging ? 2 * cand_cap * sizeof(uint2) : 0; // {segment, band} + the table slots claimed
     const size_t table_bytes = merging ? band_slots * 2 * sizeof(uint32_t) : 0;
     int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes);
@@ -1377,6 +1379,9 @@ int run_filter(const scan_args &A)
     V.nw_table = ps->NW;
     V.max_k = ps->max_k;
     V.key_len = ps->filter_key_len;
+    V.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
+    V.needle_offsets = ps->d_offsets;
+    V.text_sigma = ps->sigma;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;
@@ -1401,9 +1406,21 @@ int run_filter(const scan_args &A)
         V.n_segments = A.n_segments;
     }
     V.cand_counter = 1;
+    if (!merging && V.needle_ranks && chance >= 2048.0) {
+        // few errors, long text: drop the candidates whose whole seed does not match (chance matches of the key; a
+        // short text has too few of them to pay for the extra launch) and verify a dense list
+        hipLaunchKernelGGL(compact_candidates_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, V, d_merged,
+                           H->d_count + 3, cand_cap);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        V.cand = d_merged;
+        V.cand_counter = 3;
+        V.needle_ranks = nullptr; // already applied
+    }
     uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
     const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-candidate kernel
     const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min;
+    if (!merging && !use_wave)
+        V.needle_ranks = nullptr; // inside the lane-per-candidate kernel the check cannot shorten a wave: leave it out
     if (merging) {
         merge_params M{};
         M.cand = d_cand;
@@ -1429,6 +1446,7 @@ int run_filter(const scan_args &A)
         M.aux = d_aux;
         M.own_slot = d_aux + cand_cap;
         M.seg_owned = V.seg_owned;
+        M.V = V; // the whole-seed check reads the text and the needles through the verification parameters
         M.owner = d_band_owner;
         M.count = d_band_count;
         M.out = d_merged;

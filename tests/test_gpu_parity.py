@@ -259,7 +259,7 @@ def test_candidate_merging_with_clustered_indels(spm, ctx, oracle):
     os.environ["SPM_HIP_FILTER_MERGE"] = "0"
     try:
         hn = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22)
-        assert hn.stats().n_bands == 0 and np.array_equal(hn.view(), hb.view())
+        assert np.array_equal(hn.view(), hb.view())
     finally:
         del os.environ["SPM_HIP_FILTER_MERGE"]
 
