@@ -45,6 +45,8 @@ struct spm_ctx
     size_t scratch_bytes = 0;
     std::vector<hits_block> pool;
     std::vector<std::pair<void *, uint64_t>> jst_pool; // record buffers of journaled-sequence searches (pointer, capacity)
+    unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs
+                                              // an extra staging hop on every scan)
 };
 
 struct spm_text

@@ -1048,9 +1048,9 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
         SPM_HIP_CHECK(ctx, hipGetLastError());
     }
     SPM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
-    unsigned long long n_out = 0;
-    SPM_HIP_CHECK(ctx, hipMemcpyAsync(&n_out, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SPM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters + 8, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long n_out = ctx->h_counters[8];
     hipEventElapsedTime(&J->stats.ms_fanout, e0, e1);
     if (n_out > out_cap) {
         SPM_SET_ERR(ctx, "journaled-sequence search produced %llu hits but the buffer holds %llu; raise "

@@ -700,6 +700,7 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
         SPM_HIP_CHECK(none, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    SPM_HIP_CHECK(none, hipHostMalloc(&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
     *out = ctx.release();
     return SPM_OK;
 }
@@ -719,6 +720,8 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
     }
     for (auto &b : ctx->jst_pool)
         hipFree(b.first);
+    if (ctx->h_counters)
+        hipHostFree(ctx->h_counters);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
@@ -1586,8 +1589,8 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         if (rc != SPM_OK)
             return rc;
         // overflow check needs the counters: one small D2H copy; on overflow re-run brute force
-        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [1] candidate slots drawn, [3] bands, [5] real candidates
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long *c = ctx->h_counters; // [1] candidate slots drawn, [3] bands, [5] real candidates
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (c[1] > H->cand_cap && c[2] == 0 && c[1] <= (1ull << 25) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
             // more candidates than the buffer was sized for (short keys on a long text): the first attempt counted
@@ -1597,7 +1600,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
-            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             H->stats.main_launches = (uint32_t)patterns->fidx.size();
         }
@@ -1675,8 +1678,8 @@ static int hits_count(spm_hits *h)
 {
     spm_ctx *ctx = h->ctx;
     if (!h->counted) {
-        unsigned long long c[4] = {0, 0, 0, 0};
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long *c = ctx->h_counters;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, h->d_count, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         h->n = c[0];
         h->counted = true;
