@@ -10,7 +10,7 @@ Default workload = BASELINE.json configs[2], the one the metric is quoted on:
 N > 1 is weak scaling: the global text is N x 16 GiB, rank g scans shard g (plus window_size-1 symbols of left
 context); the needles are planted anywhere in the global text.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2] [--text-gib G] [--engine auto|brute|filter]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c3r|c2|c4|c5] [--text-gib G] [--engine auto|brute|filter]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -38,6 +38,10 @@ WORKLOADS = {
     "c3": ("myers", 100, 3, 1024, 16.0, "Myers k<=3, 1024 needles |P|=100, 16 GiB dna4 text per GPU"),
     "c2": ("shiftor", 32, 0, 1024, 1.0, "Shift-Or exact, 1024 needles |P|=32, 1 GiB dna4 text per GPU"),
     "c4": ("myers", 150, 3, 100000, 8.0, "Myers k<=3, 100k needles |P|=150, 8 GiB dna4 text per GPU (64 GiB on 8)"),
+    # C3 on a repeat-rich text: --repeat-frac of the bases inside tandem-repeat / low-complexity stretches, every 8th
+    # needle cut across one (what the q-gram filter meets on real genomes; VERDICT r01 "next" 1)
+    "c3r": ("myers", 100, 3, 1024, 16.0, "Myers k<=3, 1024 needles |P|=100, 16 GiB dna4 text per GPU with repeat "
+                                         "stretches"),
     # journaled-sequence pan-genome: text GiB = REFERENCE bases per GPU (2^27; 2^30 on 8), 64 haplotypes over it
     "c5": ("myers", 1024, 64, 256, 0.125, "multi-word Myers |P|=1024 k<=64, 256 needles, journaled pan-genome: "
                                           "64 haplotypes over a 2^27-base reference per GPU (2^30 on 8)"),
@@ -292,6 +296,21 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
     }
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (this
+    parent has not touched the GPU or imported torch), relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,7 +323,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-sample-mib", type=int, default=256)
     ap.add_argument("--packed-steps", type=int, default=10, help="steps of the packed-shadow variant (0 = skip)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default single-GPU C3 run only: skip the C2 / C4 / C5 (/ c3r) lines attached as other_configs")
+    ap.add_argument("--repeat-frac", type=float, default=0.01, help="c3r: fraction of the text inside repeat stretches")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -317,8 +342,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     backend = os.environ.get("SPM_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
     if backend == "gloo":
@@ -332,7 +356,67 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    algo, L, kmax, n_pat, gib, desc = WORKLOADS[args.workload]
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = S.Context(local_rank, stream=stream.cuda_stream)
+        env = (S, sdist, torch, dist, rank, world, dev, ctx)
+        if args.workload == "c5":
+            result = run_c5(args, *env)
+        else:
+            result = run_scan(args, *env, workload=args.workload)
+        # One driver-timed line that covers every BASELINE config: the default run (C3, one GPU) also executes C2, C4's
+        # per-GPU shard, C5 and the repeat-rich C3 text, each >= 3 timed repetitions (test/benchmark/CMakeLists.txt:12-14)
+        if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs and args.engine == "auto"
+                and args.text_gib is None and args.needles is None):
+            result["other_configs"] = other_configs(args, env)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            algo, L, kmax, n_pat, gib, _ = WORKLOADS[args.workload]
+            n_pat = args.needles if args.needles is not None else n_pat
+            n_total = (int((args.text_gib if args.text_gib is not None else gib) * 2**30) & ~1023) * world
+            try:
+                result["cpu_baseline"] = cpu_baseline(algo, L, kmax, n_pat, n_total)
+            except Exception as e:  # the oracle is test infrastructure; its absence must not hide the GPU number
+                result["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port",
+                                          "sample": f"unavailable: {e}"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def other_configs(args, env):
+    """C2, C4 (its per-GPU 8 GiB shard), C5 and c3r on this GPU, condensed to what VERDICT r01 #2 asks for."""
+    import copy
+    out = {}
+    for name, steps, warmup in (("c2", 20, 3), ("c4", 3, 1), ("c5", 10, 2), ("c3r", 5, 2)):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup = name, steps, warmup
+        a.no_cpu_baseline, a.brute_sample_mib, a.packed_steps = True, 0, 0
+        t0 = time.perf_counter()
+        try:
+            r = run_c5(a, *env) if name == "c5" else run_scan(a, *env, workload=name)
+        except Exception as e:  # one config failing must not hide the others (nor the headline)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        rf = r["roofline"]
+        o = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+             "steps": steps, "warmup": warmup, "workload": r["config"]["workload"],
+             "roofline": {k: rf[k] for k in ("achieved", "frac", "kernel", "kernel_ms", "launches_per_step",
+                                             "algorithmic_bytes_per_launch") if k in rf},
+             "hits": r["hits"], "all_planted_found": r["all_planted_found"], "fell_back": r["fell_back"],
+             "candidates": r["candidates"], "verify_ms_per_step": r["verify_ms_per_step"],
+             "setup_and_run_s": time.perf_counter() - t0}
+        for k in ("fallback_spans", "repeat_text", "needles_found_on_their_haplotype", "journaled_sequence_tree",
+                  "fanout_ms_per_step", "parity_slice"):
+            if k in r:
+                o[k] = r[k]
+        out[name] = o
+    return out
+
+
+def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
+    """Configs C2 / C3 / C4 (and c3r): one scan of this rank's text shard against the whole needle set per step."""
+    algo, L, kmax, n_pat, gib, desc = WORKLOADS[workload]
     if args.text_gib is not None:
         gib = args.text_gib
     if args.needles is not None:
@@ -342,187 +426,210 @@ def main():
     lo, hi = sdist.shard_range(n_total, rank, world)
     window = L + kmax
     ovl = 0 if lo == 0 else 1024  # >= window_size-1 symbols of left context, keeps the shard 1 KiB aligned
+    repeats = workload == "c3r"
+    rep_ppm = int(round(args.repeat_frac * 1e6)) if repeats else 0
 
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        ctx = S.Context(local_rank, stream=stream.cuda_stream)
-        if args.workload == "c5":
-            result = run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx)
-            if rank == 0:
-                print(json.dumps(result))
-            if world > 1:
-                dist.destroy_process_group()
-            return
+    if repeats:
+        # uniform text with a stated fraction of tandem-repeat / low-complexity stretches, 1/8 of the needles cut across
+        # them (libspm_amd/csrc/synth.hpp: repeat_base / synth_repeat_pattern; the oracle regenerates any slice)
+        text = ctx.generate_repeats(SEED_TEXT, lo - ovl, (hi - lo) + ovl, rep_ppm)
+        needles = [S.synth_repeat_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax, rep_ppm)[0] for p in range(n_pat)]
+    else:
         text = ctx.generate(SEED_TEXT, lo - ovl, (hi - lo) + ovl)
         needles = [S.synth_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(n_pat)]
-        s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR
-        ps = ctx.patterns(s_algo, needles, k=kmax)
-        engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
-        max_hits = max(1 << 20, 16 * n_pat)
-        # fused gather buffer: row 0 = [count, 0], rows 1.. = records; same fixed size on every rank
-        cap = 1 << 12   # small on purpose: the all-gather moves world x (cap + 1) x 16 bytes per step
-        while cap < 8 * n_pat:
-            cap <<= 1
-        hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
-        count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+    s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR
+    ps = ctx.patterns(s_algo, needles, k=kmax)
+    engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
+    max_hits = max(1 << 20, 16 * n_pat)
+    # fused gather buffer: row 0 = [count, 0], rows 1.. = records; same fixed size on every rank
+    cap = 1 << 12   # small on purpose: the all-gather moves world x (cap + 1) x 16 bytes per step
+    while cap < 8 * n_pat:
+        cap <<= 1
+    if repeats:
+        # a needle that lies inside a repeat stretch matches every long stretch of the same unit: millions of hits
+        max_hits = 1 << 26
+        cap = max_hits
+    hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
+    count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
 
-        def step():
-            h = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
-                       pos_offset=lo - ovl, max_hits=max_hits)
-            n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
-            count_host[0] = n
-            hit_buf[0].copy_(count_host, non_blocking=True)  # count
-            gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
-            return h, gathered
+    def step():
+        h = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
+                   pos_offset=lo - ovl, max_hits=max_hits)
+        n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
+        count_host[0] = n
+        hit_buf[0].copy_(count_host, non_blocking=True)  # count
+        gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
+        return h, gathered
 
-        for _ in range(args.warmup):
-            h, g = step()
-            h.close()
+    for _ in range(args.warmup):
+        h, g = step()
+        h.close()
 
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ms_main = ms_verify = 0.0
-        launches = 0
-        last = None
-        for _ in range(args.steps):
-            h, g = step()
-            st = h.stats()
-            ms_main += st.ms_main
-            ms_verify += st.ms_verify
-            launches += st.main_launches
-            last = (st, g)
-            h.close()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-
-        st, gathered = last
-        result = None
-        if rank == 0:
-            recs = sdist.split_fused(gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
-            hits = np.frombuffer(recs.tobytes(), dtype=S.HIT_DTYPE)
-            found = np.unique(hits["pattern"])
-            ms_per_step = dt / args.steps * 1e3
-            value = n_total / (dt / args.steps) / 1e9
-            k_ms = ms_main / max(launches, 1)  # average duration of one launch of the dominant kernel
-            achieved = (hi - lo) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            engine_used = {1: "brute", 2: "filter"}.get(int(st.engine_used), "?")
-            # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, corrected as the MI355X guide
-            # prescribes; profiles/pmc_traffic.json says how) -- only when it was measured on this exact config
-            traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-                if pm and pm["text_bytes_per_gpu"] == hi - lo and engine_used == "filter":
-                    traffic = pm["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-            result = {
-                "metric": {"c3": "Gbases/s scanned, Myers k<=3 |P|=100", "c2": "Gbases/s scanned, Shift-Or |P|=32",
-                           "c4": "Gbases/s scanned, Myers k<=3 |P|=150, 100k needles"}[args.workload],
-                "value": value,
-                "unit": "Gbases/s",
-                "n_gpus": world,
-                "steps": args.steps,
-                "warmup": args.warmup,
-                "ms_per_step": ms_per_step,
-                "higher_is_better": True,
-                "scaling": "weak",
-                "vs_baseline": None,
-                "dtype": "u32",
-                "data": "synthetic",
-                "config": {"workload": f"{args.workload}: {desc}", "needles": n_pat, "needle_len": L, "k": kmax,
-                           "text_bytes_per_gpu": hi - lo, "engine": engine_used,
-                           "sharding": f"text position, {world} shard(s), {window - 1}-symbol left context, hit records "
-                                       "exchanged with one fused all-gather per step" if world > 1 else "single GPU"},
-                "roofline": {
-                    "bound": "hbm",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_brute_kernel",
-                    "kernel_ms": k_ms,
-                    "algorithmic_bytes_per_launch": hi - lo,
-                    "stream_read_probe": HBM_STREAM_PROBE_GBS,
-                    "frac_of_stream_read_probe": achieved / HBM_STREAM_PROBE_GBS,
-                },
-                "hits": int(len(hits)),
-                "needles_found": int(len(found)),
-                "all_planted_found": bool(len(found) == n_pat),
-                "verify_ms_per_step": ms_verify / args.steps,
-                "candidates": int(st.n_candidates),
-                "fell_back": int(st.fell_back),
-                "lane_steps_per_s": n_pat * n_total / (dt / args.steps),
-                # what the reference's traffic model (one full text pass PER needle) would have moved
-                # in the same time -- for comparison only, NOT a roofline figure
-                "reference_equivalent_traffic_GBps": n_pat * n_total / (dt / args.steps) / 1e9,
-            }
-
-        # brute-force engine (the one-lane-per-needle kernel) on a bounded slice, for reference next to the filter
-        if rank == 0 and world == 1 and args.engine != "brute" and args.brute_sample_mib > 0:
-            nb = min(hi - lo, args.brute_sample_mib << 20)
-            hb = S.scan(ctx, text, ps, 0, nb, engine=S.ENGINE_BRUTE, max_hits=max_hits)
-            sb = hb.stats()
-            hf = S.scan(ctx, text, ps, 0, nb, engine=engine, max_hits=max_hits)
-            same = bool(np.array_equal(hb.view(), hf.view()))
-            result["brute_force_engine"] = {
-                "Gbases_per_s": nb / (sb.ms_main * 1e-3) / 1e9,
-                "lane_steps_per_s": n_pat * nb / (sb.ms_main * 1e-3),
-                "sample_bytes": nb,
-                "hits_equal_to_default_engine": same,
-                # this engine is bounded by integer-VALU issue, not HBM
-                "valu": valu_roofline(args.workload, n_pat, n_pat * nb / (sb.ms_main * 1e-3)),
-            }
-            hb.close()
-            hf.close()
-
-        # the same scan over the optional 2-bit shadow of the text (spm_hip_text_pack): a quarter of the HBM traffic.
-        # Reported next to `value`, never as `value`: the contract's algorithmic bytes are the 1-byte text.
-        if rank == 0 and world == 1 and args.packed_steps > 0 and engine_used == "filter":
-            text.pack()
-            for _ in range(2):
-                S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True, max_hits=max_hits).close()
-            torch.cuda.synchronize()
-            t0p = time.perf_counter()
-            kms = 0.0
-            for _ in range(args.packed_steps):
-                hp = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
-                            pos_offset=lo - ovl, max_hits=max_hits)
-                stp = hp.stats()
-                kms += stp.ms_main
-                vp = hp.view() if _ == args.packed_steps - 1 else None
-                hp.close()
-            torch.cuda.synchronize()
-            dtp = (time.perf_counter() - t0p) / args.packed_steps
-            result["packed_text_shadow"] = {
-                "Gbases_per_s": n_total / dtp / 1e9,
-                "ms_per_step": dtp * 1e3,
-                "kernel_ms": kms / args.packed_steps,
-                "hbm_bytes_streamed_per_launch": (hi - lo) // 4,
-                "hits_equal_to_unpacked": bool(np.array_equal(np.sort(vp, order=["pattern", "pos"]),
-                                                              np.sort(hits, order=["pattern", "pos"]))),
-                "note": "optional 2-bit re-encoding of the resident text, built once per text (+25 % HBM); "
-                        "excluded from `value` and from `roofline`",
-            }
-
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                result["cpu_baseline"] = cpu_baseline(algo, L, kmax, n_pat, n_total)
-            except Exception as e:  # the oracle is test infrastructure; its absence must not hide the GPU number
-                result["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port",
-                                          "sample": f"unavailable: {e}"}
-        print(json.dumps(result))
     if world > 1:
-        dist.destroy_process_group()
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_main = ms_verify = 0.0
+    launches = 0
+    last = None
+    for _ in range(args.steps):
+        h, g = step()
+        st = h.stats()
+        ms_main += st.ms_main
+        ms_verify += st.ms_verify
+        launches += st.main_launches
+        last = (st, g)
+        h.close()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st, gathered = last
+    if rank != 0:
+        return None
+    recs = sdist.split_fused(gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
+    hits = np.frombuffer(recs.tobytes(), dtype=S.HIT_DTYPE)
+    found = np.unique(hits["pattern"])
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total / (dt / args.steps) / 1e9
+    # average duration of one launch of the dominant kernel (HIP events on the scan's stream).  A needle set that
+    # outgrows one LDS table runs several passes per scan (C4), each streaming the whole shard
+    k_ms = ms_main / max(launches, 1)
+    achieved = (hi - lo) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    engine_used = {1: "brute", 2: "filter"}.get(int(st.engine_used), "?")
+    # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs, corrected as the MI355X guide
+    # prescribes; profiles/pmc_traffic.json says how) -- only when it was measured on this exact config
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
+        if pm and pm["text_bytes_per_gpu"] == hi - lo and engine_used == "filter":
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    result = {
+        "metric": {"c3": "Gbases/s scanned, Myers k<=3 |P|=100", "c2": "Gbases/s scanned, Shift-Or |P|=32",
+                   "c4": "Gbases/s scanned, Myers k<=3 |P|=150, 100k needles",
+                   "c3r": "Gbases/s scanned, Myers k<=3 |P|=100, repeat-rich text"}[workload],
+        "value": value,
+        "unit": "Gbases/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{workload}: {desc}", "needles": n_pat, "needle_len": L, "k": kmax,
+                   "text_bytes_per_gpu": hi - lo, "engine": engine_used,
+                   "sharding": (f"text position, {world} shard(s), {window - 1}-symbol left context, hit records "
+                                "exchanged with one fused all-gather per step (fixed-size [count | records] buffers; "
+                                "the count-then-send gatherv, libspm_amd.dist.gatherv_hits, is what C5 uses)")
+                   if world > 1 else "single GPU"},
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_brute_kernel",
+            "kernel_ms": k_ms,
+            "launches_per_step": launches / max(args.steps, 1),
+            "algorithmic_bytes_per_launch": hi - lo,
+            "whole_step_GBps": (hi - lo) / (dt / args.steps) / 1e9,
+            "whole_step_frac": (hi - lo) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "stream_read_probe": HBM_STREAM_PROBE_GBS,
+            "frac_of_stream_read_probe": achieved / HBM_STREAM_PROBE_GBS,
+        },
+        "hits": int(len(hits)),
+        "needles_found": int(len(found)),
+        "all_planted_found": bool(len(found) == n_pat),
+        "verify_ms_per_step": ms_verify / args.steps,
+        "candidates": int(st.n_candidates),
+        "fell_back": int(st.fell_back),
+        "fallback_spans": int(st.fallback_spans),
+        "lane_steps_per_s": n_pat * n_total / (dt / args.steps),
+        # what the reference's traffic model (one full text pass PER needle) would have moved
+        # in the same time -- for comparison only, NOT a roofline figure
+        "reference_equivalent_traffic_GBps": n_pat * n_total / (dt / args.steps) / 1e9,
+    }
+    if repeats:
+        result["repeat_text"] = {
+            "fraction_requested": args.repeat_frac,
+            "generator": "1024-base blocks; a block holds one stretch (16..256 bases) with probability frac*1024/136: "
+                         "half tandem repeats (unit 1..6 bases, 1/64 impurities), half low-complexity (one base 7/8); "
+                         "needles with p % 8 == 7 are cut across a stretch (random overlap), the others as in C3",
+            "fallback_symbols": int(st.fallback_symbols),
+        }
+        # parity on a slice: the filter's hits == the brute-force engine's, on 64 MiB of this text
+        nb = min(hi - lo, 64 << 20)
+        hb = S.scan(ctx, text, ps, 0, nb, engine=S.ENGINE_BRUTE, max_hits=max_hits)
+        hf = S.scan(ctx, text, ps, 0, nb, engine=engine, max_hits=max_hits)
+        vb, vf = hb.view(), hf.view()
+        result["parity_slice"] = {"bytes": nb, "hits": int(len(vf)),
+                                  "equal_to_brute_force_engine": bool(np.array_equal(vb, vf)),
+                                  "engine": {1: "brute", 2: "filter"}.get(int(hf.stats().engine_used), "?")}
+        hb.close()
+        hf.close()
+
+    # brute-force engine (the one-lane-per-needle kernel) on a bounded slice, for reference next to the filter
+    if world == 1 and args.engine != "brute" and args.brute_sample_mib > 0:
+        nb = min(hi - lo, args.brute_sample_mib << 20)
+        hb = S.scan(ctx, text, ps, 0, nb, engine=S.ENGINE_BRUTE, max_hits=max_hits)
+        sb = hb.stats()
+        hf = S.scan(ctx, text, ps, 0, nb, engine=engine, max_hits=max_hits)
+        same = bool(np.array_equal(hb.view(), hf.view()))
+        result["brute_force_engine"] = {
+            "Gbases_per_s": nb / (sb.ms_main * 1e-3) / 1e9,
+            "lane_steps_per_s": n_pat * nb / (sb.ms_main * 1e-3),
+            "sample_bytes": nb,
+            "hits_equal_to_default_engine": same,
+            # this engine is bounded by integer-VALU issue, not HBM
+            "valu": valu_roofline(workload, n_pat, n_pat * nb / (sb.ms_main * 1e-3)),
+        }
+        hb.close()
+        hf.close()
+
+    # the same scan over the optional 2-bit shadow of the text (spm_hip_text_pack): a quarter of the HBM traffic.
+    # Reported next to `value`, never as `value`: the contract's algorithmic bytes are the 1-byte text.
+    if world == 1 and args.packed_steps > 0 and engine_used == "filter":
+        text.pack()
+        for _ in range(2):
+            S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True, max_hits=max_hits).close()
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        kms = 0.0
+        for _ in range(args.packed_steps):
+            hp = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
+                        pos_offset=lo - ovl, max_hits=max_hits)
+            stp = hp.stats()
+            kms += stp.ms_main
+            vp = hp.view() if _ == args.packed_steps - 1 else None
+            hp.close()
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0p) / args.packed_steps
+        result["packed_text_shadow"] = {
+            "Gbases_per_s": n_total / dtp / 1e9,
+            "ms_per_step": dtp * 1e3,
+            "kernel_ms": kms / args.packed_steps,
+            "hbm_bytes_streamed_per_launch": (hi - lo) // 4,
+            "hits_equal_to_unpacked": bool(np.array_equal(np.sort(vp, order=["pattern", "pos"]),
+                                                          np.sort(hits, order=["pattern", "pos"]))),
+            "note": "optional 2-bit re-encoding of the resident text, built once per text (+25 % HBM); "
+                    "excluded from `value` and from `roofline`",
+        }
+    ps.close()
+    text.close()
+    del hit_buf, gathered, last, g
+    torch.cuda.empty_cache()
+    return result
 
 
 if __name__ == "__main__":

@@ -89,12 +89,18 @@ typedef struct spm_scan_stats {
     float ms_main;        /* the dominant kernel: brute-force scan, or the seed filter */
     float ms_verify;      /* filter engine: bit-vector verification of the candidates */
     uint32_t engine_used; /* spm_engine actually run */
-    uint32_t fell_back;   /* 1 if the filter engine overflowed and the brute engine re-ran the scan */
+    uint32_t fell_back;   /* 1 if the filter engine gave up on the WHOLE scan and the brute engine re-ran it (dedupe set or
+                             overflow list exhausted, or a segmented scan overflowed); see fallback_spans for the usual,
+                             span-local form */
     uint64_t n_candidates;
     uint64_t n_hits;
     uint32_t main_launches;
     uint32_t n_bands;     /* filter engine: what was actually verified -- diagonal bands after candidate merging (sets with
                              k >= 8), else the candidates whose whole seed matches the text */
+    uint32_t fallback_spans;   /* filter engine: spans of the text whose seed hits exceeded their budget (repeat-rich
+                                  stretches); only those were scanned again by the brute-force kernel */
+    uint32_t reserved;
+    uint64_t fallback_symbols; /* ... and how many text symbols that re-scan covered */
 } spm_scan_stats;
 
 /* ---- context -------------------------------------------------------------------------------------- */
@@ -111,6 +117,12 @@ int spm_hip_text_upload(spm_ctx *ctx, const uint8_t *ranks, uint64_t n, uint32_t
 int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_t n, uint32_t sigma, spm_text **out);
 /* Synthetic uniform dna4 text generated in HBM: base(i) of SURVEY.md 8(d) for i in [global_begin, +n). */
 int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, spm_text **out);
+/* Synthetic repeat-rich dna4 text (bench workload c3r): the uniform text above with `repeat_ppm` parts per million of
+ * its bases inside tandem-repeat / low-complexity stretches of 16..256 bases (libspm_amd/csrc/synth.hpp says exactly
+ * how).  spm_hip_synth_repeat_text regenerates any slice on the host; spm_hip_synth_repeat_pattern cuts needle p from
+ * it, every 8th one across a stretch. */
+int spm_hip_text_generate_repeats(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, uint32_t repeat_ppm,
+                                  spm_text **out);
 /* Optional: build a 2-bit shadow of a dna4 haystack (16 symbols per uint32, +25 % HBM).  Later seed-filter scans of
  * this text stream the shadow instead of the 1-byte ranks -- a quarter of the HBM traffic -- and return identical hits;
  * verification and the brute-force engine keep reading the original ranks.  Meant for a reference that is scanned
@@ -254,6 +266,9 @@ int spm_hip_jst_synth_variants(uint64_t seed_text, uint64_t seed_var, uint64_t r
 /* ---- synthetic needles of the benchmark configs (host side) -------------------------- */
 uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
                                uint32_t kmax, uint8_t *out);
+uint64_t spm_hip_synth_repeat_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
+                                      uint32_t kmax, uint32_t repeat_ppm, uint8_t *out);
+void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, uint64_t begin, uint64_t n, uint8_t *out);
 uint64_t spm_hip_mix64(uint64_t z);
 
 /* Host-only self-check of the seed index (no device, no context): builds the level-1 / level-2 tables exactly as

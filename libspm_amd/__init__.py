@@ -9,4 +9,4 @@ from .capi import (ALGO_HORSPOOL, ALGO_MYERS, ALGO_MYERS_PREFIX, ALGO_SHIFTOR, E
                    ENGINE_FILTER, SpmError)
 from .engine import (ALLELE_DTYPE, HIT_DTYPE, JST_HIT_DTYPE, Context, Hits, Jst, JstHits, PatternSet, Text, scan, scan_segments,
                      synth_variants,  # noqa: F401
-                     synth_pattern)
+                     synth_pattern, synth_repeat_pattern, synth_repeat_text)

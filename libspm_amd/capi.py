@@ -48,6 +48,9 @@ class ScanStats(C.Structure):
         ("n_hits", C.c_uint64),
         ("main_launches", C.c_uint32),
         ("n_bands", C.c_uint32),
+        ("fallback_spans", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("fallback_symbols", C.c_uint64),
     ]
 
 
@@ -114,6 +117,7 @@ def lib():
         "spm_hip_text_upload": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
         "spm_hip_text_wrap": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
         "spm_hip_text_generate": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+        "spm_hip_text_generate_repeats": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
         "spm_hip_text_pack": (C.c_int, [vp, vp]),
         "spm_hip_text_is_packed": (C.c_int, [vp]),
         "spm_hip_text_download": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
@@ -137,6 +141,9 @@ def lib():
         "spm_hip_hits_destroy": (None, [vp]),
         "spm_hip_synth_pattern": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.c_uint32, u8p]),
+        "spm_hip_synth_repeat_pattern": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                      C.c_uint32, C.c_uint32, u8p]),
+        "spm_hip_synth_repeat_text": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
         "spm_hip_mix64": (C.c_uint64, [C.c_uint64]),
         "spm_hip_host_selftest": (C.c_int, [C.c_int, u8p, u32p, C.c_uint32, u16p, C.c_uint32, C.POINTER(C.c_uint64)]),
         "spm_hip_version": (C.c_char_p, []),
@@ -166,13 +173,13 @@ def lib():
 
 EXPORTS = [
     "spm_hip_init", "spm_hip_destroy", "spm_hip_last_error", "spm_hip_synchronize", "spm_hip_text_upload",
-    "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_pack", "spm_hip_text_is_packed",
+    "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_generate_repeats", "spm_hip_text_pack", "spm_hip_text_is_packed",
     "spm_hip_text_download", "spm_hip_text_length",
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
     "spm_hip_hits_copy_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
-    "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
+    "spm_hip_synth_repeat_pattern", "spm_hip_synth_repeat_text", "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
     "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",
     "spm_hip_jst_hits_copy_device", "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",

@@ -51,6 +51,11 @@ struct brute_params
     spm_hit *hits;
     unsigned long long *counters; // [0] = hit count
     uint64_t hit_cap;
+    // span-local fallback of the filter engine: this launch re-scans the spans whose candidates overflowed, and must not
+    // report a hit the filter's verification already reported.  seen = the scan's dedupe set (nullptr otherwise).
+    unsigned long long *seen;
+    uint32_t seen_mask;
+    unsigned long long *overflow;
 };
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
@@ -88,6 +93,45 @@ __device__ __forceinline__ void wave_append_hits(bool is_hit, uint64_t pos, uint
             hits[idx] = h;
         }
     }
+}
+
+__host__ __device__ inline uint64_t seen_hash(uint64_t z) // splitmix64 finaliser (same function as synth.hpp's mix64)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Hit of the brute-force kernels.  `e` = exclusive end of the occurrence in text coordinates (the dedupe key of the
+// filter engine's verification), `pos` = what is reported.  Call with the wave converged.
+__device__ __forceinline__ void brute_report(const brute_params &P, bool hit, uint64_t e, uint64_t pos, uint32_t pattern,
+                                             int32_t score)
+{
+    if (P.seen) {
+        if (hit) {
+            const unsigned long long key = ((unsigned long long)pattern << 40) | (unsigned long long)e;
+            uint32_t slot = (uint32_t)seen_hash(key) & P.seen_mask;
+            bool placed = false, fresh = false;
+            for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
+                const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
+                if (old == ~0ull) {
+                    fresh = true;
+                    placed = true;
+                } else if (old == key) {
+                    placed = true;
+                } else {
+                    slot = (slot + 1) & P.seen_mask;
+                }
+            }
+            if (!placed)
+                atomicAdd(P.overflow, 1ull);
+            hit = fresh;
+        }
+        if (__ballot(hit) == 0)
+            return;
+    }
+    wave_append_hits(hit, pos, pattern, score, P.hits, P.counters, P.hit_cap);
 }
 
 // Load the dword holding text[idx..idx+4) for idx % 4 == 0, never touching bytes >= alloc.
@@ -249,8 +293,8 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
                         L.step(lane_peq + (size_t)c * NW * 64);
                         const bool hit = L.score <= my_k;
                         if (__ballot(hit) != 0)
-                            wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 + P.pos_offset, group * 64 + lane,
-                                             L.score, P.hits, P.counters, P.hit_cap);
+                            brute_report(P, hit, cbase + (uint64_t)j * 4 + s + 1,
+                                         cbase + (uint64_t)j * 4 + s + 1 + P.pos_offset, group * 64 + lane, L.score);
                     }
                 }
             } else {
@@ -267,8 +311,7 @@ __global__ __launch_bounds__(256) void myers_brute_kernel(const brute_params P)
                         L.step(lane_peq + (size_t)c * NW * 64);
                         const bool hit = L.score <= my_k;
                         if (p >= own_lo && __ballot(hit) != 0)
-                            wave_append_hits(hit, p + 1 + P.pos_offset, group * 64 + lane, L.score, P.hits,
-                                             P.counters, P.hit_cap);
+                            brute_report(P, hit, p + 1, p + 1 + P.pos_offset, group * 64 + lane, L.score);
                     }
                 }
             }
@@ -371,7 +414,7 @@ __global__ __launch_bounds__(256) void myers_cutoff_kernel(const brute_params P)
             // slow path, entered when some lane has S <= k or S >= shrink_at
             bool hit = (a == my_nw) && (S <= my_k);
             if (report && __ballot(hit) != 0)
-                wave_append_hits(hit, pos, group * 64 + lane, S, P.hits, P.counters, P.hit_cap);
+                brute_report(P, hit, pos - P.pos_offset, pos, group * 64 + lane, S);
             // shrink
             while (a > 1 && S >= my_k + (bp + 1)) {
                 uint32_t vp = 0, vn = 0;
@@ -610,8 +653,9 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
                         for (int s = 0; s < 4; ++s) {
                             const bool hit = active_lane && ((int32_t)top[s] >= 0); // bit 31 clear
                             if (__ballot(hit) != 0)
-                                wave_append_hits(hit, cbase + (uint64_t)j * 4 + s + 1 - (uint64_t)my_m + P.pos_offset,
-                                                 group * 64 + lane, 0, P.hits, P.counters, P.hit_cap);
+                                brute_report(P, hit, cbase + (uint64_t)j * 4 + s + 1,
+                                             cbase + (uint64_t)j * 4 + s + 1 - (uint64_t)my_m + P.pos_offset,
+                                             group * 64 + lane, 0);
                         }
                     }
                 }
@@ -629,8 +673,7 @@ __global__ __launch_bounds__(256) void shiftor_brute_kernel(const brute_params P
                         // an occurrence that starts before the haystack's first symbol cannot exist; with a
                         // restored state it can start in an earlier chunk, whose coordinates the caller owns
                         if (p >= own_lo && __ballot(hit) != 0)
-                            wave_append_hits(hit, p + 1 - (uint64_t)my_m + P.pos_offset, group * 64 + lane, 0,
-                                             P.hits, P.counters, P.hit_cap);
+                            brute_report(P, hit, p + 1, p + 1 - (uint64_t)my_m + P.pos_offset, group * 64 + lane, 0);
                     }
                 }
             }

@@ -59,18 +59,28 @@ struct candidate
 {
     uint64_t t;   // text index of the window start            | merged: first diagonal of the band (int64)
     uint32_t val; // pattern << 11 | offset of the window inside the pattern   | merged: pattern << 11 | band width - 1
-    uint32_t pad; // 0                                          | merged: segment index + 1
+    uint32_t pad; // diagonal range r: the key also sits at offsets up to offset + r of this needle (periodic seeds:
+                  // one entry, one candidate, verified over the diagonals t - offset - r .. t - offset)
+                  //                                            | merged: kCandMerged | (segment index + 1)
 };
+constexpr uint32_t kCandMerged = 0x80000000u;
 
 // Candidate slots are handed to the waves in chunks of 16: one atomic on the shared counter per chunk instead of one
 // per survivor (a single address takes ~100 atomics/us; 14-symbol keys on a 1.5 GiB text produce 10^5 survivors, which
 // cost 0.8 of the kernel's 1.2 ms before).  Slots a wave reserved but did not fill are marked invalid.
-constexpr uint32_t kCandChunk = 16;
+constexpr uint32_t kCandChunk = 32;
 constexpr uint32_t kCandInvalid = 0xFFFFFFFFu; // candidate.val of an unused slot (pattern index 2^21 - 1 never exists)
-// The chunk a wave is filling lives in LDS behind the level-1 table ({base lo, base hi, used, size} per wave; touched
-// only on the rare survivor path, so nothing stays live across the streaming loop): slots [base + used, base + size)
-// are free.  size = 16, or the number of survivors of one ballot if that is larger.
+// The chunk a wave is filling lives in LDS behind the level-1 table (kCandRec words per wave: {base lo, base hi, used,
+// size, candidates of the current span, span given up, span begin lo, hi}; touched only on the rare survivor path and
+// once per span, so nothing stays live across the streaming loop): slots [base + used, base + size) are free.
+// size = kCandChunk, or the number of survivors of one ballot if that is larger.
+//
+// Span budget: a span (the unit of work a wave dequeues) that produces more than `span_budget` candidates -- or meets a
+// full candidate buffer -- gives up: it emits nothing more, its text range goes to the overflow list, and the host
+// re-scans exactly those ranges with the brute-force kernel (hits deduplicated through the same `seen` set).  Repeat-rich
+// megabases then cost their own brute-force time, not a re-run of the whole scan.
 constexpr uint32_t kCandLdsSlot = 4; // words after lds_words where the per-wave chunk records start
+constexpr uint32_t kCandRec = 8;     // words per wave
 
 struct filter_params
 {
@@ -80,7 +90,8 @@ struct filter_params
     uint32_t stride;          // S in {1,2,4,8,16}
     uint32_t bitmap_words;    // power of two, <= 32768 (128 KiB)
     uint32_t n_probes;        // Bloom probes per key
-    uint32_t span_chunks;     // 1-KiB chunks per span
+    uint32_t span_chunks;     // chunks per span
+    uint32_t span_unit;       // symbols per chunk: 1024 (1-byte text) or 4096 (2-bit shadow)
     uint32_t dynamic;         // 1: waves draw spans from counters[4] instead of a static round-robin
     uint32_t queue_cap;       // 0: resolve survivors on the spot; else they are queued in LDS (strides 1 and 2)
     uint32_t key_len;         // H: symbols per key (12..16); windows are H symbols, keys 2H bits
@@ -92,10 +103,14 @@ struct filter_params
     uint32_t chd_disp_off;    // byte offset of the displacement table inside the LDS image
     const uint32_t *bitmap;   // [bitmap_words]
     const uint2 *ht;          // exact table: (key, val), val == kHtEmpty marks an empty slot
+    const uint16_t *ht_rng;   // per slot: diagonal range of the entry (candidate::pad)
     uint32_t ht_mask;
+    uint32_t span_budget;     // candidates one span may produce before it gives up
     candidate *cand;
-    unsigned long long *counters; // [1] = candidate count
+    unsigned long long *counters; // [1] = candidate slots drawn, [6] = spans that gave up, [2] = hard overflow
     uint64_t cand_cap;
+    uint64_t *ovf_spans;      // [ovf_cap][2]: {first text index, symbols} of every span that gave up
+    uint64_t ovf_cap;
 };
 
 template <int HV>
@@ -222,7 +237,36 @@ __device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint
 __device__ __forceinline__ uint32_t *cand_chunk_of(const filter_params &P, const uint32_t *lds)
 {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    return const_cast<uint32_t *>(lds) + P.lds_words + kCandLdsSlot + 4 * wave;
+    return const_cast<uint32_t *>(lds) + P.lds_words + kCandLdsSlot + kCandRec * wave;
+}
+
+// A wave starts a span: fresh budget (wave-uniform call).  `len` = symbols the span covers.
+__device__ __forceinline__ void span_open(const filter_params &P, const uint32_t *lds, uint32_t lane, uint64_t begin)
+{
+    if (lane == 0) {
+        uint32_t *ck = cand_chunk_of(P, lds);
+        ck[4] = 0;
+        ck[5] = 0;
+        ck[6] = (uint32_t)begin;
+        ck[7] = (uint32_t)(begin >> 32);
+    }
+}
+
+// the current span gives up (wave-uniform call)
+__device__ __forceinline__ void span_give_up(const filter_params &P, uint32_t *ck, uint32_t lane, uint64_t span_symbols)
+{
+    if (lane == 0) {
+        ck[5] = 1;
+        const unsigned long long i = atomicAdd(&P.counters[6], 1ull);
+        if (i < P.ovf_cap) {
+            P.ovf_spans[2 * i] = ((uint64_t)ck[7] << 32) | ck[6];
+            P.ovf_spans[2 * i + 1] = span_symbols;
+        } else {
+            atomicAdd(&P.counters[2], 1ull); // no room to remember it: the host re-runs the whole scan
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // mark the unused tail of a wave's chunk invalid (wave-uniform call)
@@ -240,13 +284,18 @@ __device__ __forceinline__ void cand_close(const filter_params &P, const uint32_
 }
 
 // Level 2 for one survivor per lane (wave-uniform call; `probing` marks the lanes that hold one): probe the exact key
-// table, append every (needle, offset) the key belongs to as a candidate.
+// table, append every (needle, offset) the key belongs to as a candidate.  Candidate slots come in chunks for every
+// stride: one atomic on the shared counter per kCandChunk candidates (a single address takes ~100 atomics/us, and a
+// repeat-rich text produces 10^6..10^7 candidates).
 template <int S>
 __device__ __forceinline__ void resolve_survivors(const filter_params &P, bool probing, uint32_t key, uint64_t t,
                                                   uint32_t lane, const uint32_t *lds)
 {
+    uint32_t *ck = cand_chunk_of(P, lds);
+    if (__builtin_amdgcn_readfirstlane(ck[5]) != 0)
+        return; // this span has given up: the brute-force kernel will scan it
     bool emit = false;
-    uint32_t val = 0;
+    uint32_t val = 0, rng = 0;
     uint32_t slot = ht_hash(key) & P.ht_mask;
     while (__ballot(probing) != 0) {
         emit = false;
@@ -258,6 +307,7 @@ __device__ __forceinline__ void resolve_survivors(const filter_params &P, bool p
                 if (e.x == key) {
                     emit = true;
                     val = e.y;
+                    rng = P.ht_rng[slot];
                 }
                 slot = (slot + 1) & P.ht_mask;
             }
@@ -265,57 +315,47 @@ __device__ __forceinline__ void resolve_survivors(const filter_params &P, bool p
         const uint64_t m = __ballot(emit);
         if (m != 0) {
             const uint32_t n = __popcll(m);
-            if constexpr (S <= 2) {
-                // strides 1 and 2 (huge needle sets, short keys) see 10^5..10^6 survivors: slots come in chunks
-                uint32_t *ck = cand_chunk_of(P, lds);
-                uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
-                if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
-                    cand_close(P, ck, lane);
-                    const uint32_t size = n > kCandChunk ? n : kCandChunk;
-                    if (lane == 0) {
-                        const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
-                        ck[0] = (uint32_t)b;
-                        ck[1] = (uint32_t)(b >> 32);
-                        ck[3] = size;
-                    }
-                    used = 0;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint64_t cbase = ((uint64_t)ck[1] << 32) | ck[0];
-                if (emit) {
-                    const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
-                    if (idx < P.cand_cap) {
-                        candidate c;
-                        c.t = t;
-                        c.val = val;
-                        c.pad = 0;
-                        P.cand[idx] = c;
-                    }
-                }
-                if (lane == 0)
-                    ck[2] = used + n;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // the larger strides see a few thousand survivors per scan: one atomic per ballot is cheaper
-                // than carrying the chunk bookkeeping through the streaming kernel (measured: C3 2.49 vs 2.60 ms)
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                unsigned long long base = 0;
-                if ((int)lane == leader)
-                    base = atomicAdd(&P.counters[1], (unsigned long long)n);
-                base = __shfl(base, leader);
-                if (emit) {
-                    const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
-                    if (idx < P.cand_cap) {
-                        candidate c;
-                        c.t = t;
-                        c.val = val;
-                        c.pad = 0;
-                        P.cand[idx] = c;
-                    }
-                }
+            uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(ck[4]) + n;
+            const uint64_t span_symbols = (uint64_t)P.span_chunks * (uint64_t)(P.span_unit);
+            if (cnt > P.span_budget) {
+                span_give_up(P, ck, lane, span_symbols);
+                return;
             }
+            if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
+                cand_close(P, ck, lane);
+                const uint32_t size = n > kCandChunk ? n : kCandChunk;
+                if (lane == 0) {
+                    const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
+                    ck[0] = (uint32_t)b;
+                    ck[1] = (uint32_t)(b >> 32);
+                    ck[2] = 0;
+                    ck[3] = size;
+                }
+                used = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint64_t cbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ck[1]) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane(ck[0]);
+            if (cbase + used + n > P.cand_cap) { // the candidate buffer is full
+                span_give_up(P, ck, lane, span_symbols);
+                return;
+            }
+            if (emit) {
+                const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
+                candidate c;
+                c.t = t;
+                c.val = val;
+                c.pad = rng;
+                P.cand[idx] = c;
+            }
+            if (lane == 0) {
+                ck[2] = used + n;
+                ck[4] = cnt;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -325,7 +365,7 @@ __device__ __forceinline__ void resolve_survivors(const filter_params &P, bool p
 // Per wave: {count, key[cap], t_lo[cap], t_hi[cap]} behind the chunk records.
 constexpr uint32_t kQueueCap = 96;
 constexpr uint32_t kQueueWords = 4 + 3 * kQueueCap; // per wave
-constexpr uint32_t kQueueLdsSlot = kCandLdsSlot + 4 * 16; // words after lds_words where the queues start
+constexpr uint32_t kQueueLdsSlot = kCandLdsSlot + kCandRec * 16; // words after lds_words where the queues start
 
 __device__ __forceinline__ uint32_t *survivor_queue_of(const filter_params &P, const uint32_t *lds)
 {
@@ -454,6 +494,8 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
     }
     // survivors: exact key table
     while (__ballot(pos_mask != 0) != 0) {
+        if (__builtin_amdgcn_readfirstlane(cand_chunk_of(P, lds)[5]) != 0)
+            break; // the span has given up
         uint64_t t = 0;
         uint32_t key = 0;
         bool probing = false;
@@ -551,11 +593,9 @@ __global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
     for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
         lds[i] = P.bitmap[i];
     if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
-        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + 4 * (threadIdx.x >> 6);
-        ck[0] = 0;
-        ck[1] = 0;
-        ck[2] = 0;
-        ck[3] = 0; // size 0: the first survivor draws a chunk
+        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + kCandRec * (threadIdx.x >> 6);
+        for (uint32_t i = 0; i < kCandRec; ++i)
+            ck[i] = 0; // size 0: the first survivor draws a chunk; no span open yet
         if (P.queue_cap != 0)
             lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
@@ -610,6 +650,7 @@ __global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
             break;
         const uint64_t c_begin = sp * span;
         const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
+        span_open(P, lds, lane, base0 + c_begin * 1024);
         // word of the lane "before lane 0": last 16 bytes of the previous chunk
         uint32_t carry_in = 0, carry_n = 0;
         {
@@ -657,13 +698,13 @@ __global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
             filter_group<S, 1, HV, SIG, KM>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
         }
+        if constexpr (S <= 2) { // queued survivors are charged to the span they came from
+            if (P.queue_cap != 0)
+                drain_survivors<S>(P, lane, lds);
+        }
         sp += n_waves;
     }
-    if constexpr (S <= 2) {
-        if (P.queue_cap != 0)
-            drain_survivors<S>(P, lane, lds);
-        cand_close(P, cand_chunk_of(P, lds), lane);
-    }
+    cand_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -696,11 +737,9 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
     for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
         lds[i] = P.bitmap[i];
     if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
-        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + 4 * (threadIdx.x >> 6);
-        ck[0] = 0;
-        ck[1] = 0;
-        ck[2] = 0;
-        ck[3] = 0; // size 0: the first survivor draws a chunk
+        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + kCandRec * (threadIdx.x >> 6);
+        for (uint32_t i = 0; i < kCandRec; ++i)
+            ck[i] = 0; // size 0: the first survivor draws a chunk; no span open yet
         if (P.queue_cap != 0)
             lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
@@ -749,6 +788,7 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
         const uint64_t c_begin = sp * span;
         const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
         const uint64_t fast_end = c_begin + (c_end - c_begin + U2 - 1) / U2 * U2; // whole groups (shadow is padded)
+        span_open(P, lds, lane, base0 + c_begin * 4096);
         // the word in front of this span's first word
         uint32_t carry_in = 0;
         {
@@ -792,13 +832,13 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
             }
             filter_words<S, NWD, HV, 4, true, KM>(P, w, prev, nv, base0 + ch * 4096, lane, lds, idx_mask);
         }
+        if constexpr (S <= 2) {
+            if (P.queue_cap != 0)
+                drain_survivors<S>(P, lane, lds);
+        }
         sp += n_waves;
     }
-    if constexpr (S <= 2) {
-        if (P.queue_cap != 0)
-            drain_survivors<S>(P, lane, lds);
-        cand_close(P, cand_chunk_of(P, lds), lane);
-    }
+    cand_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -847,8 +887,8 @@ struct verify_params
 // the 16-symbol key (C4: 800 000 of 1 140 000; C3: 16 000 of 20 000); they fail this check after ~1.3 symbols.
 __device__ __forceinline__ bool seed_intact(const verify_params &P, const candidate &c, int64_t hay_b, int64_t hay_e)
 {
-    if (!P.needle_ranks)
-        return true;
+    if (!P.needle_ranks || c.pad != 0)
+        return true; // (a candidate with a diagonal range stands for several offsets of a periodic seed: kept)
     const uint32_t pat = c.val >> 11, x = c.val & 0x7FF;
     const seed_plan sp = plan_seeds((uint32_t)P.m[pat], (uint32_t)P.k[pat]);
     const uint32_t o = (x / sp.q) * sp.q; // start of the seed inside the needle
@@ -894,13 +934,14 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
             continue; // a slot its wave reserved but did not fill
         ++n_valid;
         const uint32_t pat = c.val >> 11;
-        const bool merged = c.pad != 0;
-        const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF);
-        const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : 0;
+        const bool merged = (c.pad & kCandMerged) != 0;
+        // raw candidate: diagonals t - x - r .. t - x (r = c.pad);  merged band: diagonals t .. t + span
+        const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF) + (int64_t)c.pad;
+        const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : (int64_t)c.pad;
         const int64_t m = P.m[pat];
         const int64_t k = P.k[pat];
-        const int64_t d = (int64_t)c.t - x; // diagonal: needle position 0 <-> text index d
-        // exclusive end positions this candidate answers for: e in [d+m-k, d+m+k] (a band: up to diagonal d+span)
+        const int64_t d = (int64_t)c.t - x; // first diagonal: needle position 0 <-> text index d
+        // exclusive end positions this candidate answers for: e in [d+m-k, d+span+m+k]
         int64_t e_lo = d + m - k;
         int64_t e_hi = d + m + k + span;
         // ownership: last symbol e-1 in [scan_begin, scan_end)
@@ -909,7 +950,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
             // every segment is a haystack of its own: find the one holding the key window, clamp to it
             uint64_t lo = 0, hi = P.n_segments; // invariant: seg_offsets[lo] <= t < seg_offsets[hi]
             if (merged) {
-                lo = c.pad - 1;
+                lo = (c.pad & ~kCandMerged) - 1;
             } else {
                 while (hi - lo > 1) {
                     const uint64_t mid = (lo + hi) >> 1;
@@ -1066,9 +1107,9 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             ++n_valid;
         if (active) {
             pat = c.val >> 11;
-            const bool merged = c.pad != 0;
-            const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF);
-            const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : 0;
+            const bool merged = (c.pad & kCandMerged) != 0;
+            const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF) + (int64_t)c.pad;
+            const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : (int64_t)c.pad;
             m = P.m[pat];
             k = P.k[pat];
             const int64_t d = (int64_t)c.t - x;
@@ -1078,7 +1119,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             if (P.seg_offsets) {
                 uint64_t lo = 0, hi = P.n_segments;
                 if (merged) {
-                    lo = c.pad - 1;
+                    lo = (c.pad & ~kCandMerged) - 1;
                 } else {
                     while (hi - lo > 1) {
                         const uint64_t mid = (lo + hi) >> 1;
@@ -1413,7 +1454,7 @@ __global__ void merge_select_kernel(const merge_params P)
                 candidate c;
                 c.t = (uint64_t)(sb - (int64_t)P.max_m + (int64_t)band * P.Bw); // first diagonal of the band
                 c.val = (pat << 11) | (P.Bw + (uint32_t)P.k[pat]);                 // its last diagonal: + Bw + k
-                c.pad = a.x + 1;
+                c.pad = kCandMerged | (a.x + 1);
                 P.out[idx] = c;
             }
         }

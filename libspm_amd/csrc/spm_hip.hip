@@ -38,11 +38,15 @@ struct filter_index
     uint32_t chd_slot_mask = 0, chd_bucket_shift = 0, chd_disp_off = 0;
     uint32_t ht_mask = 0;
     uint64_t n_keys = 0;
+    uint64_t n_entries = 0;  // entries of the exact table after identical (key, needle) pairs were merged
+    uint32_t max_range = 0;  // largest diagonal range of a merged entry
     uint32_t *d_bitmap = nullptr;
     uint2 *d_ht = nullptr;
+    uint16_t *d_ht_rng = nullptr;
     // host copies, kept only by spm_hip_host_selftest (no device involved)
     std::vector<uint32_t> h_image;
     std::vector<uint2> h_ht;
+    std::vector<uint16_t> h_rng;
 };
 
 static thread_local bool g_index_host_only = false;
@@ -77,6 +81,7 @@ struct spm_patterns
     uint32_t *d_offsets = nullptr;  // ... and where each needle starts
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
+    uint32_t filter_max_range = 0; // largest diagonal range over all passes (end-position slots of the verification)
 };
 
 static uint32_t next_pow2(uint32_t x)
@@ -177,6 +182,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                 for (filter_index &F : ps->fidx) {
                     hipFree(F.d_bitmap);
                     hipFree(F.d_ht);
+                    hipFree(F.d_ht_rng);
                 }
                 ps->fidx.clear();
                 return SPM_OK; // too many passes to be worth it: brute force
@@ -190,6 +196,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                 for (filter_index &G : ps->fidx) {
                     hipFree(G.d_bitmap);
                     hipFree(G.d_ht);
+                    hipFree(G.d_ht_rng);
                 }
                 ps->fidx.clear();
                 return SPM_OK;
@@ -197,13 +204,17 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
             ps->fidx.push_back(F);
             p0 = p1;
         }
-        for (const filter_index &F : ps->fidx)
+        ps->filter_max_range = 0;
+        for (const filter_index &F : ps->fidx) {
             dense_failure = dense_failure || (want_chd && F.hash_variant != 2);
+            ps->filter_max_range = std::max(ps->filter_max_range, F.max_range);
+        }
         if (!dense_failure || attempt == 2)
             return SPM_OK;
         for (filter_index &F : ps->fidx) {
             hipFree(F.d_bitmap);
             hipFree(F.d_ht);
+            hipFree(F.d_ht_rng);
         }
         ps->fidx.clear();
     }
@@ -238,6 +249,29 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     F.n_keys = keys.size();
     if (F.n_keys == 0)
         return SPM_OK;
+    // A periodic seed puts the same key at several offsets of one needle (a homopolymer run: at every shift of every
+    // seed).  Such entries are merged into one with a diagonal range: a text window then yields ONE candidate per needle,
+    // verified over the diagonals of all the offsets, instead of one per offset.  (Not for sets whose candidates are
+    // merged per diagonal band: the band count works on single diagonals.)
+    std::vector<uint16_t> ranges(keys.size(), 0);
+    const bool band_merging = ps->max_k >= kMergeMinK && ps->max_k <= 1000;
+    if (!band_merging && env_int("SPM_HIP_FILTER_DEDUPE", 1) != 0) {
+        std::sort(keys.begin(), keys.end(), [](const kv &a, const kv &b) { return a.key != b.key ? a.key < b.key : a.val < b.val; });
+        size_t w = 0;
+        for (size_t i = 0; i < keys.size();) {
+            size_t j = i + 1;
+            while (j < keys.size() && keys[j].key == keys[i].key && (keys[j].val >> 11) == (keys[i].val >> 11))
+                ++j;
+            keys[w] = keys[i];
+            ranges[w] = (uint16_t)((keys[j - 1].val & 0x7FF) - (keys[i].val & 0x7FF));
+            F.max_range = std::max<uint32_t>(F.max_range, ranges[w]);
+            ++w;
+            i = j;
+        }
+        keys.resize(w);
+        ranges.resize(w);
+    }
+    F.n_entries = keys.size();
     F.stride = S;
     F.n_probes = (uint32_t)std::max(1, std::min(4, env_int("SPM_HIP_FILTER_PROBES", 4)));
     F.hash_variant = (uint32_t)std::max(0, std::min(2, env_int("SPM_HIP_FILTER_HASH", 2)));
@@ -336,25 +370,31 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     F.lds_words = (uint32_t)image.size();
     const uint32_t words = F.lds_words;
     const std::vector<uint32_t> &bitmap = image;
-    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_keys * 2));
+    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_entries * 2));
     F.ht_mask = ht_size - 1;
     std::vector<uint2> ht(ht_size, make_uint2(0, kHtEmpty));
-    for (const kv &e : keys) {
+    std::vector<uint16_t> rng(ht_size, 0);
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const kv &e = keys[i];
         uint32_t slot = ht_hash(e.key) & F.ht_mask;
         while (ht[slot].y != kHtEmpty)
             slot = (slot + 1) & F.ht_mask;
         ht[slot] = make_uint2(e.key, e.val);
+        rng[slot] = ranges[i];
     }
     if (g_index_host_only) {
         F.h_image = bitmap;
         F.h_ht = ht;
+        F.h_rng = rng;
         F.ok = true;
         return SPM_OK;
     }
     SPM_HIP_CHECK(ctx, hipMalloc(&F.d_bitmap, words * sizeof(uint32_t)));
     SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint2)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht_rng, ht_size * sizeof(uint16_t)));
     SPM_HIP_CHECK(ctx, hipMemcpy(F.d_bitmap, bitmap.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
     SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht, ht.data(), ht_size * sizeof(uint2), hipMemcpyHostToDevice));
+    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht_rng, rng.data(), ht_size * sizeof(uint16_t), hipMemcpyHostToDevice));
     F.ok = true;
     return SPM_OK;
 }
@@ -525,6 +565,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
+        hipFree(F.d_ht_rng);
     }
     delete p;
 }
@@ -829,6 +870,35 @@ extern "C" int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t globa
     return SPM_OK;
 }
 
+extern "C" int spm_hip_text_generate_repeats(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n,
+                                             uint32_t repeat_ppm, spm_text **out)
+{
+    if (!ctx || !out || (global_begin & 31) || repeat_ppm > 130000) {
+        SPM_SET_ERR(ctx, "spm_hip_text_generate_repeats: global_begin must be a multiple of 32, repeat_ppm <= 130000");
+        return SPM_E_INVALID;
+    }
+    spm_text *t = nullptr;
+    int rc = text_alloc(ctx, n, 4, &t);
+    if (rc != SPM_OK)
+        return rc;
+    if (n) {
+        const uint64_t n_q = (n + 15) / 16;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_q + 255) / 256, (uint64_t)ctx->n_cu * 32);
+        hipLaunchKernelGGL(synth_repeat_text_kernel, dim3(grid), dim3(256), 0, ctx->stream, t->d, seed, repeat_ppm,
+                           global_begin, n);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            SPM_SET_ERR(ctx, "text generate failed: %s", hipGetErrorString(e));
+            spm_hip_text_destroy(t);
+            return SPM_E_HIP;
+        }
+    }
+    *out = t;
+    return SPM_OK;
+}
+
 extern "C" int spm_hip_text_pack(spm_ctx *ctx, spm_text *text)
 {
     if (!ctx || !text) {
@@ -920,7 +990,14 @@ struct scan_args
     const uint32_t *d_seg_owned = nullptr;   // optional per-segment offset of the first wanted end symbol (filter engine)
     uint64_t cand_cap_override = 0;          // retry after a candidate overflow: the count the first attempt needed
     std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
+    // span-local fallback: the filter run leaves these for the brute-force re-scan of the spans that gave up
+    unsigned long long *d_seen = nullptr;
+    uint32_t seen_mask = 0;
+    uint64_t *d_ovf = nullptr;               // overflow list in the scratch buffer: {begin, symbols} per span
+    const std::vector<uint64_t> *tiles = nullptr; // brute pass over an explicit tile table {scan_lo, own_lo, own_hi}
 };
+
+constexpr uint64_t kOvfCap = 1ull << 17; // spans the overflow list holds (2 MiB); beyond: whole-scan fallback
 
 template <int NW>
 void launch_brute_nw(const spm_patterns *ps, const brute_params &P, dim3 grid, dim3 block, size_t lds,
@@ -1058,6 +1135,11 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
     P.hits = A.hits->d_hits;
     P.counters = A.hits->d_count + (report ? 0 : 3); // a state-only pass counts into a dummy slot
     P.hit_cap = report ? A.hits->cap : 0;
+    if (A.tiles) { // re-scan of the filter's overflowed spans: report only what its verification has not reported
+        P.seen = A.d_seen;
+        P.seen_mask = A.seen_mask;
+        P.overflow = A.hits->d_count + 2;
+    }
 
     const size_t lds_per_wave = (size_t)(ps->sigma + 1) * ps->NW * 64 * sizeof(uint32_t);
     uint32_t wpw = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / lds_per_wave));
@@ -1086,7 +1168,17 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
         tile = 4;
     P.tile = (uint32_t)std::min<uint64_t>(tile, 0xFFFFFF00u);
     P.n_tiles = (uint32_t)std::max<uint64_t>(1, (range + P.tile - 1) / P.tile);
-    if (!A.seg_offsets && A.d_seg_offsets) {
+    if (A.tiles) {
+        P.n_tiles = (uint32_t)(A.tiles->size() / 3);
+        uint64_t *d_tab = nullptr;
+        SPM_HIP_CHECK(ctx, hipMalloc(&d_tab, A.tiles->size() * sizeof(uint64_t)));
+        hipFree(A.hits->d_aux[0]);
+        A.hits->d_aux[0] = d_tab;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_tab, A.tiles->data(), A.tiles->size() * sizeof(uint64_t),
+                                          hipMemcpyHostToDevice, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        P.tile_tab = d_tab;
+    } else if (!A.seg_offsets && A.d_seg_offsets) {
         // brute-force run over a device-resident segment table (fallback of the journaled-sequence search)
         scan_args &W = const_cast<scan_args &>(A);
         W.seg_host.resize(A.n_segments + 1);
@@ -1095,7 +1187,7 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         W.seg_offsets = W.seg_host.data();
     }
-    if (A.seg_offsets) {
+    if (A.seg_offsets && !A.tiles) {
         // every segment is its own haystack: tiles never cross a segment, warm-up stays inside it
         std::vector<uint64_t> tab;
         for (uint64_t s = 0; s < A.n_segments; ++s) {
@@ -1154,15 +1246,17 @@ int run_filter(const scan_args &A)
     spm_hits *H = A.hits;
     // scratch: candidates + dedupe set
     const uint64_t kmax = ps->max_k;
-    constexpr uint64_t kCandMax = 1ull << 25; // 512 MiB of candidates: beyond that the brute engine takes over
+    constexpr uint64_t kCandMax = 1ull << 26; // 1 GiB of candidates: beyond that spans give up (brute-force re-scan)
     uint64_t cand_cap = std::max<uint64_t>(4096, 8ull * ps->n * (kmax + 1)); // a handful of true seed hits per needle
+    // real texts are not uniform: room for the seed hits of repeat stretches (one candidate per 256 symbols)
+    cand_cap = std::max<uint64_t>(cand_cap, (A.end - A.begin) / 256);
     // chance hits of short keys: windows looked at x keys / 4^key_len, per pass (negligible for 16-symbol keys)
     double chance = 0;
     for (const filter_index &F : ps->fidx)
         chance += (double)(A.end - A.begin) / std::max(1u, F.stride) * (double)F.n_keys / std::pow(4.0, (double)F.key_len);
     cand_cap = std::max<uint64_t>(cand_cap, (uint64_t)(2.0 * chance));
     cand_cap = std::max<uint64_t>(cand_cap, ps->cand_hint + ps->cand_hint / 4);
-    cand_cap += (uint64_t)ctx->n_cu * 16 * kCandChunk; // slots are drawn in chunks of 16 per wave: room for the tails
+    cand_cap += (uint64_t)ctx->n_cu * 16 * kCandChunk; // slots are drawn in chunks per wave: room for the tails
     cand_cap = std::min(cand_cap, kCandMax);
     if (A.cand_cap_override)
         cand_cap = A.cand_cap_override;
@@ -1171,7 +1265,7 @@ int run_filter(const scan_args &A)
         cand_cap = (uint64_t)cc;
     // dedupe set: one key per reported hit, so twice the hit capacity is room enough
     uint64_t seen_slots = 1u << 16;
-    while (seen_slots < 2 * std::min<uint64_t>(cand_cap * (2 * kmax + 1), std::max<uint64_t>(H->cap, 1)))
+    while (seen_slots < 2 * std::min<uint64_t>(cand_cap * (2 * kmax + 1 + ps->filter_max_range), std::max<uint64_t>(H->cap, 1)))
         seen_slots <<= 1;
     const size_t cand_bytes = cand_cap * sizeof(candidate);
     const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
@@ -1183,7 +1277,8 @@ int run_filter(const scan_args &A)
     const size_t merged_bytes = 2 * cand_bytes; // merged bands, or the compacted candidate list
     const size_t aux_bytes = merging ? 2 * cand_cap * sizeof(uint2) : 0; // {segment, band} + the table slots claimed
     const size_t table_bytes = merging ? band_slots * 2 * sizeof(uint32_t) : 0;
-    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes);
+    const size_t ovf_bytes = kOvfCap * 2 * sizeof(uint64_t);
+    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes + ovf_bytes);
     if (rc != SPM_OK)
         return rc;
     candidate *d_cand = (candidate *)ctx->d_scratch;
@@ -1192,6 +1287,13 @@ int run_filter(const scan_args &A)
     uint2 *d_aux = (uint2 *)((uint8_t *)d_merged + merged_bytes);
     uint32_t *d_band_owner = (uint32_t *)((uint8_t *)d_aux + aux_bytes);
     uint32_t *d_band_count = d_band_owner + band_slots;
+    uint64_t *d_ovf = (uint64_t *)((uint8_t *)d_band_owner + table_bytes);
+    {
+        scan_args &W = const_cast<scan_args &>(A);
+        W.d_seen = d_seen;
+        W.seen_mask = (uint32_t)(seen_slots - 1);
+        W.d_ovf = d_ovf;
+    }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
     if (merging) {
         SPM_HIP_CHECK(ctx, hipMemsetAsync(d_band_owner, 0xFF, band_slots * sizeof(uint32_t), ctx->stream));
@@ -1208,6 +1310,8 @@ int run_filter(const scan_args &A)
     P.cand = d_cand;
     P.counters = H->d_count;
     P.cand_cap = cand_cap;
+    P.ovf_spans = d_ovf;
+    P.ovf_cap = kOvfCap;
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
     for (size_t fi = 0; fi < ps->fidx.size(); ++fi) {
     const filter_index &F = ps->fidx[fi];
@@ -1222,6 +1326,7 @@ int run_filter(const scan_args &A)
     P.n_probes = F.n_probes;
     P.bitmap = F.d_bitmap;
     P.ht = F.d_ht;
+    P.ht_rng = F.d_ht_rng;
     P.ht_mask = F.ht_mask;
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
@@ -1231,7 +1336,7 @@ int run_filter(const scan_args &A)
     const uint32_t threads = (uint32_t)std::max(
         64, std::min(use_packed ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one candidate-chunk record (4 words) per wave
-    size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * 16;
+    size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4;
     // strides 1 and 2: survivors are queued in LDS and resolved 64 at a time, if the queues fit beside the table
     P.queue_cap = 0;
     {
@@ -1256,6 +1361,15 @@ int run_filter(const scan_args &A)
         span = (uint64_t)fs;
     span = (span + 7) & ~7ull; // whole groups of chunks
     P.span_chunks = (uint32_t)span;
+    P.span_unit = 1024;
+    // candidates a span may produce before it gives up and is re-scanned by the brute-force kernel: one per 4 symbols
+    // costs the verification about what the re-scan would
+    {
+        const int sb = env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0);
+        P.span_budget = sb > 0 ? (uint32_t)sb : (uint32_t)std::max<uint64_t>(256, span * 1024 / 4);
+        if (A.seg_offsets || A.d_seg_offsets)
+            P.span_budget = 0xFFFFFFFFu; // segmented scans fall back as a whole (tiles would have to follow the segments)
+    }
     // span dequeue: per wave while the dequeue rate stays far below what one atomic word sustains (~88/us, i.e.
     // spans >= 192 KiB at 7 TB/s), per workgroup otherwise (measured: C3 2.52 vs 2.59 ms, C2 0.88 vs 0.20 ms)
     const int dyn = env_int("SPM_HIP_FILTER_DYN", -1);
@@ -1321,6 +1435,9 @@ int run_filter(const scan_args &A)
         pspan = std::min<uint64_t>(std::max<uint64_t>(pspan, 4), 4096);
         pspan = (pspan + 3) & ~3ull;
         Q.span_chunks = (uint32_t)pspan;
+        Q.span_unit = 4096;
+        if (env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0) <= 0 && Q.span_budget != 0xFFFFFFFFu)
+            Q.span_budget = (uint32_t)std::max<uint64_t>(256, pspan * 4096 / 4);
         Q.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (pspan >= 48 ? 1u : 2u);
         const uint4 *shadow = reinterpret_cast<const uint4 *>(A.text->d_packed);
 #define LAUNCH_PACKED2(S, U2, KM)                                                                                      \
@@ -1381,6 +1498,7 @@ int run_filter(const scan_args &A)
     V.sigma = ps->sigma;
     V.nw_table = ps->NW;
     V.max_k = ps->max_k;
+    V.max_span = ps->filter_max_range; // raw candidates of merged (periodic) entries answer for a range of diagonals
     V.key_len = ps->filter_key_len;
     V.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
     V.needle_offsets = ps->d_offsets;
@@ -1589,29 +1707,106 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         if (rc != SPM_OK)
             return rc;
         // overflow check needs the counters: one small D2H copy; on overflow re-run brute force
-        unsigned long long *c = ctx->h_counters; // [1] candidate slots drawn, [3] bands, [5] real candidates
+        // [0] hits, [1] candidate slots drawn, [2] hard overflow, [3] bands, [5] real candidates, [6] spans that gave up
+        unsigned long long *c = ctx->h_counters;
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (c[1] > H->cand_cap && c[2] == 0 && c[1] <= (1ull << 25) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
-            // more candidates than the buffer was sized for (short keys on a long text): the first attempt counted
-            // them, the second has room
-            A.cand_cap_override = c[1] + c[1] / 8 + 4096;
+        const bool segmented = seg_offsets || d_seg_offsets;
+        // Spans gave up because the candidate BUFFER was full (not their own budget), and a larger buffer is affordable:
+        // the first attempt counted the demand, the second has room.  (Segmented scans have no span budget: the whole
+        // count is known.)
+        if (c[1] > H->cand_cap && c[2] == 0 && H->cand_cap < (1ull << 26) && c[0] <= H->cap &&
+            !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
+            A.cand_cap_override = std::min<uint64_t>(1ull << 26, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, segmented ? 0 : 4 * H->cand_cap));
             SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            H->stats.main_launches = 0;
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
             SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            H->stats.main_launches = (uint32_t)patterns->fidx.size();
         }
         H->stats.n_candidates = c[5];
         H->stats.n_bands = (uint32_t)c[3];
-        if (c[1] <= H->cand_cap)
+        if (c[6] == 0 && c[1] <= H->cand_cap)
             patterns->cand_hint = std::max<uint64_t>(patterns->cand_hint, c[1]);
-        if (c[1] > H->cand_cap || c[2] != 0) {
+        if (c[0] > H->cap) {
+            // more hits than the caller's buffer takes: that is the caller's overflow (SPM_E_OVERFLOW from the views,
+            // the count so far in stats.n_hits), not a reason to scan again
+            H->n = c[0];
+            H->counted = true;
+        } else if (c[2] != 0 || (segmented && c[1] > H->cand_cap)) {
+            // the dedupe set or the overflow list ran out, or a segmented scan overflowed: the whole range again, brute force
             H->stats.fell_back = 1;
             use_filter = false;
             SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        } else if (c[6] != 0) {
+            // ---- span-local fallback: only the spans that gave up are scanned again, by the brute-force kernel ----
+            const uint64_t n_ovf = c[6];
+            std::vector<uint64_t> ov(2 * n_ovf);
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(ov.data(), A.d_ovf, ov.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            // a window that starts in span [b, b + len) belongs to occurrences whose last symbol lies in
+            // [b - 16, b + len + max_window): those are scanned again (clipped to the owned range), merged where they touch
+            std::vector<std::pair<uint64_t, uint64_t>> rg;
+            rg.reserve(n_ovf);
+            for (uint64_t i = 0; i < n_ovf; ++i) {
+                const uint64_t b = ov[2 * i], len = ov[2 * i + 1];
+                const uint64_t lo = std::max<uint64_t>(begin, b >= 16 ? b - 16 : 0);
+                const uint64_t hi = std::min<uint64_t>(end, b + len + patterns->max_window);
+                if (lo < hi)
+                    rg.emplace_back(lo, hi);
+            }
+            std::sort(rg.begin(), rg.end());
+            std::vector<std::pair<uint64_t, uint64_t>> mg;
+            for (const auto &r : rg) {
+                if (!mg.empty() && r.first <= mg.back().second)
+                    mg.back().second = std::max(mg.back().second, r.second);
+                else
+                    mg.push_back(r);
+            }
+            uint64_t total = 0;
+            for (const auto &r : mg)
+                total += r.second - r.first;
+            const uint64_t warm = patterns->max_window > 0 ? patterns->max_window - 1 : 0;
+            // tile length: enough tiles to fill the machine, long enough that the warm-up stays a small share
+            const uint64_t want_tiles = (uint64_t)ctx->n_cu * 32 / std::max(1u, patterns->n_groups) + 1;
+            uint64_t tile = std::max<uint64_t>(std::max<uint64_t>(1024, (warm * 8 + 255) & ~255ull), (total / want_tiles + 255) & ~255ull);
+            tile = std::min<uint64_t>(tile, 1u << 20);
+            std::vector<uint64_t> tab;
+            for (const auto &r : mg)
+                for (uint64_t lo = r.first; lo < r.second; lo += tile) {
+                    const uint64_t hi = std::min(lo + tile, r.second);
+                    tab.push_back(lo >= A.ctx_begin + warm ? lo - warm : A.ctx_begin);
+                    tab.push_back(lo);
+                    tab.push_back(hi);
+                }
+            H->stats.fallback_spans = (uint32_t)std::min<uint64_t>(n_ovf, 0xFFFFFFFFu);
+            if (!tab.empty()) {
+                if (tab.size() / 3 > 0xFFFFFFFFull) {
+                    SPM_SET_ERR(ctx, "span-local fallback: too many tiles");
+                    return SPM_E_UNSUPPORTED;
+                }
+                A.tiles = &tab;
+                rc = run_brute(A, begin, end, A.ctx_begin, nullptr, nullptr, true, false);
+                A.tiles = nullptr;
+                if (rc != SPM_OK)
+                    return rc;
+                H->stats.main_launches--; // (run_brute counts itself as a main launch: ms_main stays the filter's)
+                SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream)); // the re-scan counts as verification time
+                SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+                SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            H->stats.fallback_symbols = total;
+            if (c[2] != 0 && c[0] <= H->cap) {
+                // the dedupe set ran out during the re-scan: start over with the brute-force engine
+                H->stats.fell_back = 1;
+                use_filter = false;
+                SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            } else {
+                H->n = c[0];
+                H->counted = true;
+            }
         } else {
             H->n = c[0];
             H->counted = true;
@@ -1812,6 +2007,18 @@ extern "C" uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat,
     return synth_pattern(seed_text, seed_pat, n_total, p, L, kmax, out);
 }
 
+extern "C" uint64_t spm_hip_synth_repeat_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p,
+                                                 uint32_t L, uint32_t kmax, uint32_t repeat_ppm, uint8_t *out)
+{
+    return synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm, out);
+}
+
+extern "C" void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, uint64_t begin, uint64_t n, uint8_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = repeat_base(seed, repeat_ppm, begin + i);
+}
+
 extern "C" uint64_t spm_hip_mix64(uint64_t z) { return mix64(z); }
 
 // Host-only self-check of the seed index (no device, no context): builds the tables exactly as
@@ -1832,6 +2039,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     for (uint32_t p = 0; p < n_patterns; ++p) {
         ps.m[p] = (int32_t)(offsets[p + 1] - offsets[p]);
         ps.k[p] = (ps.is_myers() && k) ? k[p] : 0;
+        ps.max_k = std::max<uint32_t>(ps.max_k, (uint32_t)ps.k[p]);
     }
     g_index_host_only = true;
     const int rc = build_filter_index(nullptr, &ps);
@@ -1867,8 +2075,9 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
             const uint2 e = F.h_ht[slot];
             if (e.y == kHtEmpty)
                 return false;
-            if (e.x == key && e.y == val)
-                return true;
+            if (e.x == key && (e.y >> 11) == (val >> 11) && (e.y & 0x7FF) <= (val & 0x7FF) &&
+                (val & 0x7FF) <= (e.y & 0x7FF) + F.h_rng[slot])
+                return true; // the entry, or the merged entry whose diagonal range covers this offset
             slot = (slot + 1) & F.ht_mask;
         }
     };

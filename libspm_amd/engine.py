@@ -64,6 +64,13 @@ class Context:
         _check(capi.lib().spm_hip_text_generate(self._h, seed, global_begin, n, C.byref(h)), self._h)
         return Text(self, h, 4)
 
+    def generate_repeats(self, seed: int, global_begin: int, n: int, repeat_ppm: int) -> "Text":
+        """Synthetic repeat-rich dna4 text (bench workload c3r; csrc/synth.hpp)."""
+        h = C.c_void_p()
+        _check(capi.lib().spm_hip_text_generate_repeats(self._h, seed, global_begin, n, repeat_ppm, C.byref(h)),
+               self._h)
+        return Text(self, h, 4)
+
     # ---- needles ----
     def patterns(self, algo: int, needles, k=0, sigma: int = 4) -> "PatternSet":
         needles = [np.ascontiguousarray(p, dtype=np.uint8) for p in needles]
@@ -238,6 +245,19 @@ def synth_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, k
     o = capi.lib().spm_hip_synth_pattern(seed_text, seed_pat, n_total, p, L, kmax,
                                          out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out, int(o)
+
+
+def synth_repeat_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, kmax: int, repeat_ppm: int):
+    out = np.empty(L, dtype=np.uint8)
+    o = capi.lib().spm_hip_synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm,
+                                                out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out, int(o)
+
+
+def synth_repeat_text(seed: int, repeat_ppm: int, begin: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    capi.lib().spm_hip_synth_repeat_text(seed, repeat_ppm, begin, n, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
 
 
 ALLELE_DTYPE = np.dtype([("pos", "<u8"), ("ref_len", "<u4"), ("alt_len", "<u4"), ("alt_off", "<u8")])

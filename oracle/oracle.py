@@ -67,6 +67,8 @@ def lib():
         L.spm_oracle_mix64.argtypes = [C.c_uint64]
         L.spm_oracle_text.restype = None
         L.spm_oracle_text.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u8p]
+        L.spm_oracle_repeat_text.restype = None
+        L.spm_oracle_repeat_text.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p]
         L.spm_oracle_pattern.restype = C.c_uint64
         L.spm_oracle_pattern.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
         L.spm_oracle_checksum.restype = C.c_uint64
@@ -160,6 +162,12 @@ def sellers(text, pat, k, mode=INFIX, col=None, text_offset=0):
 def text(seed, begin, n):
     out = np.empty(n, dtype=np.uint8)
     lib().spm_oracle_text(seed, begin, n, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def repeat_text(seed, ppm, begin, n):
+    out = np.empty(n, dtype=np.uint8)
+    lib().spm_oracle_repeat_text(seed, ppm, begin, n, out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out
 
 

@@ -343,6 +343,39 @@ void spm_oracle_text(uint64_t seed, uint64_t begin, uint64_t n, uint8_t *out)
         out[i] = text_base(seed, begin + i);
 }
 
+/* Repeat-rich text of bench workload c3r (product copy: libspm_amd/csrc/synth.hpp, repeat_base).  1024-base blocks;
+ * block b holds one stretch with probability ppm * 1024 / 136 / 1e6, decided by the low 32 bits of the block hash:
+ * length 16 * (1 + bits 32..35), offset (bits 36..51) mod (1024 - length + 1); bit 52 = kind.
+ *   kind 0: tandem repeat, unit length 1 + (hash >> 53) mod 6, unit symbols = bit pairs of a second hash, one base in 64
+ *           replaced by a different one;   kind 1: dominant base (hash >> 53) & 3 with probability 7/8, else uniform. */
+void spm_oracle_repeat_text(uint64_t seed, uint32_t ppm, uint64_t begin, uint64_t n, uint8_t *out)
+{
+    const uint64_t thr = ((uint64_t)ppm * 1024ull * 4294967296ull) / (136ull * 1000000ull);
+    for (uint64_t t = 0; t < n; ++t) {
+        const uint64_t i = begin + t;
+        const uint64_t h = spm_oracle_mix64((seed ^ 0x7E9EA7ull) + (i >> 10) * 0x9E3779B97F4A7C15ull);
+        const uint32_t len = 16u * (1u + (uint32_t)((h >> 32) & 15));
+        const uint32_t off = (uint32_t)((h >> 36) & 0xFFFF) % (1024u - len + 1u);
+        const uint32_t in = (uint32_t)(i & 1023);
+        if ((h & 0xFFFFFFFFull) >= thr || in < off || in >= off + len) {
+            out[t] = text_base(seed, i);
+            continue;
+        }
+        const uint32_t j = in - off;
+        const uint64_t h2 = spm_oracle_mix64(h);
+        const uint32_t x = (uint32_t)(spm_oracle_mix64(h2 + 1 + (j >> 3)) >> (8 * (j & 7))) & 0xFF;
+        if (((h >> 52) & 1) == 0) {
+            const uint32_t u = 1u + (uint32_t)((h >> 53) % 6);
+            uint32_t sym = (uint32_t)(h2 >> (2 * (j % u))) & 3u;
+            if ((x & 63u) == 0)
+                sym = (sym + 1u + (x >> 6) % 3u) & 3u;
+            out[t] = (uint8_t)sym;
+        } else {
+            out[t] = (uint8_t)((x & 7u) != 0 ? ((h >> 53) & 3u) : ((x >> 3) & 3u));
+        }
+    }
+}
+
 static inline uint64_t pat_rnd(uint64_t seed_pat, uint32_t p, uint32_t t)
 {
     return spm_oracle_mix64(seed_pat + ((uint64_t)p << 16) + t);

@@ -98,6 +98,9 @@ size_t spm_oracle_sellers(const uint8_t *text, size_t n, const uint8_t *pat, siz
 /* ---- synthetic inputs ---- */
 uint64_t spm_oracle_mix64(uint64_t z);
 void spm_oracle_text(uint64_t seed, uint64_t begin, uint64_t n, uint8_t *out);
+/* repeat-rich text of bench workload c3r: `ppm` parts per million of the bases inside tandem-repeat / low-complexity
+ * stretches (see spm_oracle.c) */
+void spm_oracle_repeat_text(uint64_t seed, uint32_t ppm, uint64_t begin, uint64_t n, uint8_t *out);
 /* pattern p of length L with e = p mod (kmax+1) planted edits; returns planted source offset */
 uint64_t spm_oracle_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
                             uint32_t kmax, uint8_t *out);

@@ -1,0 +1,136 @@
+"""Repeat-rich texts: the seed filter must stay exact AND stay the engine -- a span whose seed hits exceed its budget
+is scanned again by the brute-force kernel on its own, the rest of the scan keeps the filter's result
+(VERDICT r01 "what's weak" 1).  Everything is checked against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED_TEXT, SEED_PAT = 0x5EED0001, 0x5EED0002
+
+
+def _hits_list(h):
+    return [(int(a), int(b), int(c)) for a, b, c in zip(h["pattern"], h["pos"], h["score"])]
+
+
+def _oracle(O, T, needles, k):
+    out = []
+    for p, nd in enumerate(needles):
+        r = O.myers(T, nd, k)
+        out += [(p, int(a), int(s)) for a, s in zip(r["pos"], r["score"])]
+    return sorted(out)
+
+
+def _setup(spm, ctx, oracle, n, ppm, n_pat, L=100, k=3):
+    text = ctx.generate_repeats(SEED_TEXT, 0, n, ppm)
+    T = text.download(0, n)
+    assert np.array_equal(T, oracle.repeat_text(SEED_TEXT, ppm, 0, n)), "device generator != oracle generator"
+    needles = [spm.synth_repeat_pattern(SEED_TEXT, SEED_PAT, n, p, L, k, ppm)[0] for p in range(n_pat)]
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    assert ps.filterable
+    return text, T, needles, ps
+
+
+@pytest.mark.parametrize("ppm", [10000, 50000, 120000])
+def test_repeat_rich_text_filter_equals_brute_and_oracle(spm, ctx, oracle, ppm):
+    """c3r-shaped: needles cut across tandem-repeat / low-complexity stretches; default budgets -> no fallback at all."""
+    n = 1 << 22
+    text, T, needles, ps = _setup(spm, ctx, oracle, n, ppm, 64)
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+    st = hf.stats()
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 24)
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
+    assert np.array_equal(hf.view(), hb.view())
+    assert _hits_list(hf.view()) == _oracle(oracle, T, needles, 3)
+    assert len(np.unique(hf.view()["pattern"])) == len(needles)
+
+
+@pytest.mark.parametrize("budget", [1, 4, 64])
+def test_partial_fallback_is_exact(spm, ctx, oracle, budget):
+    """A tiny per-span budget forces spans to give up; only those are brute-scanned, hits stay bit-exact and unique."""
+    n = 1 << 22
+    text, T, needles, ps = _setup(spm, ctx, oracle, n, 50000, 64)
+    os.environ["SPM_HIP_FILTER_SPAN_BUDGET"] = str(budget)
+    try:
+        hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+        st = hf.stats()
+        got = hf.view()
+    finally:
+        del os.environ["SPM_HIP_FILTER_SPAN_BUDGET"]
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
+    assert st.fallback_spans > 0 and 0 < st.fallback_symbols
+    if budget >= 64:
+        assert st.fallback_symbols < n  # partial: the quiet spans kept the filter's result
+    want = _oracle(oracle, T, needles, 3)
+    assert _hits_list(got) == want
+    assert len(set(_hits_list(got))) == len(got)  # nothing reported twice (filter + re-scan share the dedupe set)
+
+
+def test_partial_fallback_with_left_context_and_offset(spm, ctx, oracle):
+    """Shard semantics survive the fallback: sub-range with left context, pos_offset, hits owned by last symbol."""
+    n = 1 << 21
+    text, T, needles, ps = _setup(spm, ctx, oracle, n, 80000, 32)
+    b, e = 300001, n - 7777
+    os.environ["SPM_HIP_FILTER_SPAN_BUDGET"] = "2"
+    try:
+        hf = spm.scan(ctx, text, ps, b, e, engine=spm.ENGINE_FILTER, left_context=True, pos_offset=1000, max_hits=1 << 24)
+        st = hf.stats()
+        got = _hits_list(hf.view())
+    finally:
+        del os.environ["SPM_HIP_FILTER_SPAN_BUDGET"]
+    assert st.fallback_spans > 0
+    want = [(p, pos + 1000, s) for p, pos, s in _oracle(oracle, T, needles, 3) if b < pos <= e]
+    assert got == want
+
+
+def test_periodic_needles_merged_index_entries(spm, ctx, oracle):
+    """Homopolymer / short-period needles: every shift of every seed has the same key.  The index keeps one entry per
+    (key, needle) with a diagonal range; verification covers all the diagonals it stands for."""
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    for at in range(5000, n - 1000, 9973):                 # runs of A, (CA)n, (GAT)n of varying length
+        ln = 60 + (at % 240)
+        unit = [[0], [1, 0], [2, 0, 3]][at % 3]
+        T[at:at + ln] = np.resize(np.array(unit, np.uint8), ln)
+    T[rng.integers(0, n, 2000)] ^= 2                       # impurities
+    needles = [np.zeros(100, np.uint8), np.resize(np.array([1, 0], np.uint8), 100),
+               np.resize(np.array([2, 0, 3], np.uint8), 100),
+               np.concatenate([rng.integers(0, 4, 60, dtype=np.uint8), np.zeros(40, np.uint8)]),  # unique + poly-A tail
+               np.concatenate([np.resize(np.array([0, 1], np.uint8), 50), rng.integers(0, 4, 50, dtype=np.uint8)])]
+    for nd in needles[3:]:
+        T[777777:777777 + 100] = nd                       # (the second overwrites the first: one planted at least)
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+    st = hf.stats()
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
+    want = _oracle(oracle, T, needles, 3)
+    assert _hits_list(hf.view()) == want
+    assert len(want) > 1000
+    # the same with the merged entries switched off: more candidates, same hits
+    os.environ["SPM_HIP_FILTER_DEDUPE"] = "0"
+    try:
+        ps0 = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+    finally:
+        del os.environ["SPM_HIP_FILTER_DEDUPE"]
+    h0 = spm.scan(ctx, text, ps0, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+    assert np.array_equal(h0.view(), hf.view())
+    assert h0.stats().n_candidates > 4 * st.n_candidates
+
+
+def test_hit_overflow_is_reported_not_rescanned(spm, ctx, oracle):
+    """More hits than max_hits: SPM_E_OVERFLOW from the view with the count so far, no brute-force re-run of the scan."""
+    n = 1 << 20
+    T = np.zeros(n, dtype=np.uint8)
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, [np.zeros(100, np.uint8)], k=3)
+    h = spm.scan(ctx, text, ps, engine=spm.ENGINE_AUTO, max_hits=1000)
+    st = h.stats()
+    assert st.n_hits > 1000 and st.fell_back == 0
+    with pytest.raises(spm.SpmError, match="raise spm_scan_opts.max_hits"):
+        h.view()
+    h2 = spm.scan(ctx, text, ps, engine=spm.ENGINE_AUTO, max_hits=1 << 21)
+    assert len(h2.view()) == n - 100 + 3 + 1
