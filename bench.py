@@ -326,6 +326,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default single-GPU C3 run only: skip the C2 / C4 / C5 (/ c3r) lines attached as other_configs")
     ap.add_argument("--repeat-frac", type=float, default=0.01, help="c3r: fraction of the text inside repeat stretches")
+    ap.add_argument("--repeat-needle-every", type=int, default=64,
+                    help="c3r: besides the needles that cross a stretch by chance (uniform cut positions: ~1.7 %% of them at "
+                         "1 %% repeats), every N-th needle is cut across a stretch on purpose (0: none)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -433,7 +436,8 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         # uniform text with a stated fraction of tandem-repeat / low-complexity stretches, 1/8 of the needles cut across
         # them (libspm_amd/csrc/synth.hpp: repeat_base / synth_repeat_pattern; the oracle regenerates any slice)
         text = ctx.generate_repeats(SEED_TEXT, lo - ovl, (hi - lo) + ovl, rep_ppm)
-        needles = [S.synth_repeat_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax, rep_ppm)[0] for p in range(n_pat)]
+        needles = [S.synth_repeat_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax, rep_ppm, args.repeat_needle_every)[0]
+                   for p in range(n_pat)]
     else:
         text = ctx.generate(SEED_TEXT, lo - ovl, (hi - lo) + ovl)
         needles = [S.synth_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(n_pat)]
@@ -553,6 +557,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         "all_planted_found": bool(len(found) == n_pat),
         "verify_ms_per_step": ms_verify / args.steps,
         "candidates": int(st.n_candidates),
+        "bands_verified": int(st.n_bands),
         "fell_back": int(st.fell_back),
         "fallback_spans": int(st.fallback_spans),
         "lane_steps_per_s": n_pat * n_total / (dt / args.steps),
@@ -563,9 +568,11 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     if repeats:
         result["repeat_text"] = {
             "fraction_requested": args.repeat_frac,
+            "needles_across_a_stretch_on_purpose": (n_pat // args.repeat_needle_every) if args.repeat_needle_every else 0,
             "generator": "1024-base blocks; a block holds one stretch (16..256 bases) with probability frac*1024/136: "
                          "half tandem repeats (unit 1..6 bases, 1/64 impurities), half low-complexity (one base 7/8); "
-                         "needles with p % 8 == 7 are cut across a stretch (random overlap), the others as in C3",
+                         "needles are cut at uniform positions of this text (crossing stretches at the natural rate) and "
+                         "every --repeat-needle-every-th one across a stretch on purpose (random overlap)",
             "fallback_symbols": int(st.fallback_symbols),
         }
         # parity on a slice: the filter's hits == the brute-force engine's, on 64 MiB of this text

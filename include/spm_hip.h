@@ -120,7 +120,7 @@ int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, ui
 /* Synthetic repeat-rich dna4 text (bench workload c3r): the uniform text above with `repeat_ppm` parts per million of
  * its bases inside tandem-repeat / low-complexity stretches of 16..256 bases (libspm_amd/csrc/synth.hpp says exactly
  * how).  spm_hip_synth_repeat_text regenerates any slice on the host; spm_hip_synth_repeat_pattern cuts needle p from
- * it, every 8th one across a stretch. */
+ * it at a uniformly random position, and every `across_every`-th one (0: none) across a stretch on purpose. */
 int spm_hip_text_generate_repeats(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, uint32_t repeat_ppm,
                                   spm_text **out);
 /* Optional: build a 2-bit shadow of a dna4 haystack (16 symbols per uint32, +25 % HBM).  Later seed-filter scans of
@@ -267,7 +267,7 @@ int spm_hip_jst_synth_variants(uint64_t seed_text, uint64_t seed_var, uint64_t r
 uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
                                uint32_t kmax, uint8_t *out);
 uint64_t spm_hip_synth_repeat_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
-                                      uint32_t kmax, uint32_t repeat_ppm, uint8_t *out);
+                                      uint32_t kmax, uint32_t repeat_ppm, uint32_t across_every, uint8_t *out);
 void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, uint64_t begin, uint64_t n, uint8_t *out);
 uint64_t spm_hip_mix64(uint64_t z);
 

@@ -142,7 +142,7 @@ def lib():
         "spm_hip_synth_pattern": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                C.c_uint32, u8p]),
         "spm_hip_synth_repeat_pattern": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
-                                                      C.c_uint32, C.c_uint32, u8p]),
+                                                      C.c_uint32, C.c_uint32, C.c_uint32, u8p]),
         "spm_hip_synth_repeat_text": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
         "spm_hip_mix64": (C.c_uint64, [C.c_uint64]),
         "spm_hip_host_selftest": (C.c_int, [C.c_int, u8p, u32p, C.c_uint32, u16p, C.c_uint32, C.POINTER(C.c_uint64)]),

@@ -45,6 +45,11 @@ struct spm_ctx
     size_t scratch_bytes = 0;
     std::vector<hits_block> pool;
     std::vector<std::pair<void *, uint64_t>> jst_pool; // record buffers of journaled-sequence searches (pointer, capacity)
+    // band table of the filter engine: empty between scans (see run_filter)
+    unsigned long long *d_band_keys = nullptr;
+    unsigned long long *d_band_val = nullptr;
+    uint64_t band_slots = 0;
+    bool band_dirty = false;
     unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs
                                               // an extra staging hop on every scan)
 };
@@ -67,7 +72,8 @@ struct spm_hits
     spm_hit *d_hits = nullptr;
     unsigned long long *d_count = nullptr; // [0] hits, [1] candidates, [2] overflow flags
     uint64_t cap = 0;
-    uint64_t cand_cap = 0;
+    uint64_t cand_cap = 0; // survivor list capacity of the filter run
+    uint64_t band_cap = 0;
     uint64_t n = 0;
     bool counted = false;
     bool sorted_host = false;

@@ -55,28 +55,52 @@ __host__ __device__ inline seed_plan plan_seeds(uint32_t m, uint32_t k)
 }
 constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
 
-struct candidate
+// What the streaming kernel leaves behind: one record per text window whose key passed level 1 (practically: a real
+// seed key).  The exact key table in L2 is NOT consulted while streaming -- an L2 round trip per survivor stalls a wave
+// for microseconds, and a repeat-rich text has 10^7 of them; resolve_kernel looks them up afterwards, one lane per
+// survivor, at full occupancy.
+struct survivor
 {
-    uint64_t t;   // text index of the window start            | merged: first diagonal of the band (int64)
-    uint32_t val; // pattern << 11 | offset of the window inside the pattern   | merged: pattern << 11 | band width - 1
-    uint32_t pad; // diagonal range r: the key also sits at offsets up to offset + r of this needle (periodic seeds:
-                  // one entry, one candidate, verified over the diagonals t - offset - r .. t - offset)
-                  //                                            | merged: kCandMerged | (segment index + 1)
+    uint32_t key;
+    uint32_t t_lo, t_hi; // text index of the window start; t_hi == kSurvInvalid marks a reserved but unused slot
+    uint32_t pad;        // pass (needle sub-batch) whose level-1 table it passed
 };
-constexpr uint32_t kCandMerged = 0x80000000u;
+constexpr uint32_t kSurvInvalid = 0xFFFFFFFFu;
 
-// Candidate slots are handed to the waves in chunks of 16: one atomic on the shared counter per chunk instead of one
-// per survivor (a single address takes ~100 atomics/us; 14-symbol keys on a 1.5 GiB text produce 10^5 survivors, which
-// cost 0.8 of the kernel's 1.2 ms before).  Slots a wave reserved but did not fill are marked invalid.
-constexpr uint32_t kCandChunk = 32;
-constexpr uint32_t kCandInvalid = 0xFFFFFFFFu; // candidate.val of an unused slot (pattern index 2^21 - 1 never exists)
-// The chunk a wave is filling lives in LDS behind the level-1 table (kCandRec words per wave: {base lo, base hi, used,
-// size, candidates of the current span, span given up, span begin lo, hi}; touched only on the rare survivor path and
-// once per span, so nothing stays live across the streaming loop): slots [base + used, base + size) are free.
-// size = kCandChunk, or the number of survivors of one ballot if that is larger.
+struct pass_entry // exact key table of one pass, in L2
+{
+    const uint4 *ht; // {key, val = pattern << 11 | offset, seed signature, range code}; val == kHtEmpty: empty slot
+    uint32_t ht_mask;
+    uint32_t pad;
+};
+
+// What verification works on: a band of diagonals of one needle in one haystack (segment) that collected enough seed hits.
+// Bands are Bw diagonals wide, counted from `max_m` diagonals before the haystack's first symbol (so they are never
+// negative); sets whose needles carry surplus seeds (k >= kMergeMinK) extend every band by k diagonals into the next one,
+// so that the intact seeds of one occurrence always share a band.
+struct band_rec
+{
+    uint32_t slot; // band table slot (seed-hit count; reset by the verification)
+    uint32_t val;  // pattern << 11 | unused;  kBandInvalid marks a reserved but unused list slot
+    uint32_t seg;  // segment index (0 for unsegmented scans)
+    uint32_t band; // band index inside the haystack
+};
+constexpr uint32_t kBandInvalid = 0xFFFFFFFFu;
+constexpr unsigned long long kBandEmpty = ~0ull;
+
+// Slots of the survivor and band lists are handed to the waves in chunks: one atomic on the shared counter per chunk
+// instead of one per ballot (a single address takes ~100 atomics/us).  Chunks grow as a wave keeps drawing -- 32, 64, ..
+// 1024 -- so a quiet text costs a few hundred wasted slots and a repeat-rich one (10^7 survivors) a few thousand atomics.
+// Slots a wave reserved but did not fill are marked invalid.
+constexpr uint32_t kChunkMin = 32;
+constexpr uint32_t kChunkMax = 1024;
+// The chunk a wave of the streaming kernel is filling lives in LDS behind the level-1 table (kCandRec words per wave:
+// {base lo, base hi, used, size, survivors of the current span, span given up, span begin lo, hi}; touched only on the
+// rare survivor path and once per span, so nothing stays live across the streaming loop): slots [base + used, base + size)
+// are free.
 //
-// Span budget: a span (the unit of work a wave dequeues) that produces more than `span_budget` candidates -- or meets a
-// full candidate buffer -- gives up: it emits nothing more, its text range goes to the overflow list, and the host
+// Span budget: a span (the unit of work a wave dequeues) that produces more than `span_budget` survivors -- or meets a
+// full survivor buffer -- gives up: it emits nothing more, its text range goes to the overflow list, and the host
 // re-scans exactly those ranges with the brute-force kernel (hits deduplicated through the same `seen` set).  Repeat-rich
 // megabases then cost their own brute-force time, not a re-run of the whole scan.
 constexpr uint32_t kCandLdsSlot = 4; // words after lds_words where the per-wave chunk records start
@@ -93,7 +117,6 @@ struct filter_params
     uint32_t span_chunks;     // chunks per span
     uint32_t span_unit;       // symbols per chunk: 1024 (1-byte text) or 4096 (2-bit shadow)
     uint32_t dynamic;         // 1: waves draw spans from counters[4] instead of a static round-robin
-    uint32_t queue_cap;       // 0: resolve survivors on the spot; else they are queued in LDS (strides 1 and 2)
     uint32_t key_len;         // H: symbols per key (12..16); windows are H symbols, keys 2H bits
     uint32_t key_mask;        // (1 << 2H) - 1
     uint32_t hash_variant;    // 0/1: Bloom cascade with mul / xor-shift hashes, 2: perfect-hash fingerprints
@@ -102,13 +125,11 @@ struct filter_params
     uint32_t chd_bucket_shift; // bucket = x >> shift
     uint32_t chd_disp_off;    // byte offset of the displacement table inside the LDS image
     const uint32_t *bitmap;   // [bitmap_words]
-    const uint2 *ht;          // exact table: (key, val), val == kHtEmpty marks an empty slot
-    const uint16_t *ht_rng;   // per slot: diagonal range of the entry (candidate::pad)
-    uint32_t ht_mask;
-    uint32_t span_budget;     // candidates one span may produce before it gives up
-    candidate *cand;
-    unsigned long long *counters; // [1] = candidate slots drawn, [6] = spans that gave up, [2] = hard overflow
-    uint64_t cand_cap;
+    uint32_t span_budget;     // survivors one span may produce before it gives up
+    uint32_t pass;            // which sub-batch of the needle set this launch filters for (survivor::pad)
+    survivor *surv;
+    unsigned long long *counters; // [1] = survivor slots drawn, [6] = spans that gave up, [2] = hard overflow
+    uint64_t surv_cap;
     uint64_t *ovf_spans;      // [ovf_cap][2]: {first text index, symbols} of every span that gave up
     uint64_t ovf_cap;
 };
@@ -240,7 +261,7 @@ __device__ __forceinline__ uint32_t *cand_chunk_of(const filter_params &P, const
     return const_cast<uint32_t *>(lds) + P.lds_words + kCandLdsSlot + kCandRec * wave;
 }
 
-// A wave starts a span: fresh budget (wave-uniform call).  `len` = symbols the span covers.
+// A wave starts a span: fresh budget (wave-uniform call).
 __device__ __forceinline__ void span_open(const filter_params &P, const uint32_t *lds, uint32_t lane, uint64_t begin)
 {
     if (lane == 0) {
@@ -253,14 +274,14 @@ __device__ __forceinline__ void span_open(const filter_params &P, const uint32_t
 }
 
 // the current span gives up (wave-uniform call)
-__device__ __forceinline__ void span_give_up(const filter_params &P, uint32_t *ck, uint32_t lane, uint64_t span_symbols)
+__device__ __forceinline__ void span_give_up(const filter_params &P, uint32_t *ck, uint32_t lane)
 {
     if (lane == 0) {
         ck[5] = 1;
         const unsigned long long i = atomicAdd(&P.counters[6], 1ull);
         if (i < P.ovf_cap) {
             P.ovf_spans[2 * i] = ((uint64_t)ck[7] << 32) | ck[6];
-            P.ovf_spans[2 * i + 1] = span_symbols;
+            P.ovf_spans[2 * i + 1] = (uint64_t)P.span_chunks * (uint64_t)P.span_unit;
         } else {
             atomicAdd(&P.counters[2], 1ull); // no room to remember it: the host re-runs the whole scan
         }
@@ -270,127 +291,70 @@ __device__ __forceinline__ void span_give_up(const filter_params &P, uint32_t *c
 }
 
 // mark the unused tail of a wave's chunk invalid (wave-uniform call)
-__device__ __forceinline__ void cand_close(const filter_params &P, const uint32_t *ck, uint32_t lane)
+__device__ __forceinline__ void surv_close(const filter_params &P, const uint32_t *ck, uint32_t lane)
 {
     const uint32_t used = ck[2], size = ck[3];
-    const uint64_t idx = (((uint64_t)ck[1] << 32) | ck[0]) + used + lane;
-    if (used + lane < size && idx < P.cand_cap) {
-        candidate c;
-        c.t = 0;
-        c.val = kCandInvalid;
-        c.pad = 0;
-        P.cand[idx] = c;
-    }
+    const uint64_t base = ((uint64_t)ck[1] << 32) | ck[0];
+    for (uint32_t i = used + lane; i < size; i += 64)
+        if (base + i < P.surv_cap) {
+            survivor sv;
+            sv.key = 0;
+            sv.t_lo = 0;
+            sv.t_hi = kSurvInvalid;
+            sv.pad = 0;
+            P.surv[base + i] = sv;
+        }
 }
 
-// Level 2 for one survivor per lane (wave-uniform call; `probing` marks the lanes that hold one): probe the exact key
-// table, append every (needle, offset) the key belongs to as a candidate.  Candidate slots come in chunks for every
-// stride: one atomic on the shared counter per kCandChunk candidates (a single address takes ~100 atomics/us, and a
-// repeat-rich text produces 10^6..10^7 candidates).
-template <int S>
-__device__ __forceinline__ void resolve_survivors(const filter_params &P, bool probing, uint32_t key, uint64_t t,
-                                                  uint32_t lane, const uint32_t *lds)
+// Record the survivors of one wave step (wave-uniform call; `has` marks the lanes that hold one).
+__device__ __forceinline__ void emit_survivors(const filter_params &P, bool has, uint32_t key, uint64_t t, uint32_t lane,
+                                               const uint32_t *lds)
 {
+    const uint64_t m = __ballot(has);
+    if (m == 0)
+        return;
     uint32_t *ck = cand_chunk_of(P, lds);
-    if (__builtin_amdgcn_readfirstlane(ck[5]) != 0)
-        return; // this span has given up: the brute-force kernel will scan it
-    bool emit = false;
-    uint32_t val = 0, rng = 0;
-    uint32_t slot = ht_hash(key) & P.ht_mask;
-    while (__ballot(probing) != 0) {
-        emit = false;
-        if (probing) {
-            const uint2 e = P.ht[slot];
-            if (e.y == kHtEmpty) {
-                probing = false;
-            } else {
-                if (e.x == key) {
-                    emit = true;
-                    val = e.y;
-                    rng = P.ht_rng[slot];
-                }
-                slot = (slot + 1) & P.ht_mask;
-            }
-        }
-        const uint64_t m = __ballot(emit);
-        if (m != 0) {
-            const uint32_t n = __popcll(m);
-            uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(ck[4]) + n;
-            const uint64_t span_symbols = (uint64_t)P.span_chunks * (uint64_t)(P.span_unit);
-            if (cnt > P.span_budget) {
-                span_give_up(P, ck, lane, span_symbols);
-                return;
-            }
-            if (used + n > (uint32_t)__builtin_amdgcn_readfirstlane(ck[3])) { // wave-uniform: close, draw the next
-                cand_close(P, ck, lane);
-                const uint32_t size = n > kCandChunk ? n : kCandChunk;
-                if (lane == 0) {
-                    const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)size);
-                    ck[0] = (uint32_t)b;
-                    ck[1] = (uint32_t)(b >> 32);
-                    ck[2] = 0;
-                    ck[3] = size;
-                }
-                used = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            const uint64_t cbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ck[1]) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readfirstlane(ck[0]);
-            if (cbase + used + n > P.cand_cap) { // the candidate buffer is full
-                span_give_up(P, ck, lane, span_symbols);
-                return;
-            }
-            if (emit) {
-                const uint64_t idx = cbase + used + __popcll(m & ((1ull << lane) - 1));
-                candidate c;
-                c.t = t;
-                c.val = val;
-                c.pad = rng;
-                P.cand[idx] = c;
-            }
-            if (lane == 0) {
-                ck[2] = used + n;
-                ck[4] = cnt;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+    const uint32_t n = __popcll(m);
+    uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane(ck[2]);
+    const uint32_t size = (uint32_t)__builtin_amdgcn_readfirstlane(ck[3]);
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(ck[4]) + n;
+    if (cnt > P.span_budget) {
+        span_give_up(P, ck, lane);
+        return;
     }
-}
-
-// Strides 1 and 2 meet 10^5..10^6 survivors per scan.  Resolving each one where it turns up costs the whole wave an L2
-// round trip per survivor (~3 us); instead they are queued in LDS (key + text position) and resolved 64 at a time.
-// Per wave: {count, key[cap], t_lo[cap], t_hi[cap]} behind the chunk records.
-constexpr uint32_t kQueueCap = 96;
-constexpr uint32_t kQueueWords = 4 + 3 * kQueueCap; // per wave
-constexpr uint32_t kQueueLdsSlot = kCandLdsSlot + kCandRec * 16; // words after lds_words where the queues start
-
-__device__ __forceinline__ uint32_t *survivor_queue_of(const filter_params &P, const uint32_t *lds)
-{
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    return const_cast<uint32_t *>(lds) + P.lds_words + kQueueLdsSlot + kQueueWords * wave;
-}
-
-template <int S>
-__device__ __forceinline__ void drain_survivors(const filter_params &P, uint32_t lane, const uint32_t *lds)
-{
-    uint32_t *q = survivor_queue_of(P, lds);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(q[0]);
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t e = base + lane;
-        const bool have = e < n;
-        const uint32_t key = have ? q[4 + e] : 0u;
-        const uint64_t t = have ? (((uint64_t)q[4 + 2 * kQueueCap + e] << 32) | q[4 + kQueueCap + e]) : 0ull;
-        resolve_survivors<S>(P, have, key, t, lane, lds);
+    if (used + n > size) { // close this chunk, draw the next (twice as large, up to kChunkMax)
+        surv_close(P, ck, lane);
+        uint32_t next = size * 2 < kChunkMin ? kChunkMin : (size * 2 > kChunkMax ? kChunkMax : size * 2);
+        next = next < n ? n : next;
+        if (lane == 0) {
+            const unsigned long long b = atomicAdd(&P.counters[1], (unsigned long long)next);
+            ck[0] = (uint32_t)b;
+            ck[1] = (uint32_t)(b >> 32);
+            ck[2] = 0;
+            ck[3] = next;
+        }
+        used = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0)
-        q[0] = 0;
+    const uint64_t cbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ck[1]) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane(ck[0]);
+    if (cbase + used + n > P.surv_cap) { // the survivor buffer is full
+        span_give_up(P, ck, lane);
+        return;
+    }
+    if (has) {
+        survivor sv;
+        sv.key = key;
+        sv.t_lo = (uint32_t)t;
+        sv.t_hi = (uint32_t)(t >> 32);
+        sv.pad = P.pass;
+        P.surv[cbase + used + __popcll(m & ((1ull << lane) - 1))] = sv;
+    }
+    if (lane == 0) {
+        ck[2] = used + n;
+        ck[4] = cnt;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -492,13 +456,13 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
             }
         }
     }
-    // survivors: exact key table
+    // survivors: recorded for resolve_kernel (one per wave step and lane until every lane's mask is empty)
     while (__ballot(pos_mask != 0) != 0) {
         if (__builtin_amdgcn_readfirstlane(cand_chunk_of(P, lds)[5]) != 0)
             break; // the span has given up
         uint64_t t = 0;
         uint32_t key = 0;
-        bool probing = false;
+        bool has = false;
         if (pos_mask != 0) {
             const int bit = __ffs(pos_mask) - 1;
             pos_mask &= pos_mask - 1;
@@ -519,34 +483,10 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
             const int64_t ts = (int64_t)wpos - 16 + d;
             if (ts >= (int64_t)P.lo && (uint64_t)ts + P.key_len <= P.hi) {
                 t = (uint64_t)ts;
-                probing = true;
+                has = true;
             }
         }
-        if (S <= 2 && P.queue_cap != 0) {
-            // queue them; the wave resolves 64 at a time
-            const uint64_t m = __ballot(probing);
-            if (m != 0) {
-                uint32_t *q = survivor_queue_of(P, lds);
-                uint32_t qn = (uint32_t)__builtin_amdgcn_readfirstlane(q[0]);
-                const uint32_t n = __popcll(m);
-                if (qn + n > kQueueCap) {
-                    drain_survivors<S>(P, lane, lds);
-                    qn = 0;
-                }
-                if (probing) {
-                    const uint32_t e = qn + __popcll(m & ((1ull << lane) - 1));
-                    q[4 + e] = key;
-                    q[4 + kQueueCap + e] = (uint32_t)t;
-                    q[4 + 2 * kQueueCap + e] = (uint32_t)(t >> 32);
-                }
-                if (lane == 0)
-                    q[0] = qn + n;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
-            resolve_survivors<S>(P, probing, key, t, lane, lds);
-        }
+        emit_survivors(P, has, key, t, lane, lds);
     }
 }
 
@@ -596,8 +536,6 @@ __global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
         uint32_t *ck = lds + P.lds_words + kCandLdsSlot + kCandRec * (threadIdx.x >> 6);
         for (uint32_t i = 0; i < kCandRec; ++i)
             ck[i] = 0; // size 0: the first survivor draws a chunk; no span open yet
-        if (P.queue_cap != 0)
-            lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
     __syncthreads();
 
@@ -698,13 +636,9 @@ __global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
             filter_group<S, 1, HV, SIG, KM>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
         }
-        if constexpr (S <= 2) { // queued survivors are charged to the span they came from
-            if (P.queue_cap != 0)
-                drain_survivors<S>(P, lane, lds);
-        }
         sp += n_waves;
     }
-    cand_close(P, cand_chunk_of(P, lds), lane);
+    surv_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -740,8 +674,6 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
         uint32_t *ck = lds + P.lds_words + kCandLdsSlot + kCandRec * (threadIdx.x >> 6);
         for (uint32_t i = 0; i < kCandRec; ++i)
             ck[i] = 0; // size 0: the first survivor draws a chunk; no span open yet
-        if (P.queue_cap != 0)
-            lds[P.lds_words + kQueueLdsSlot + kQueueWords * (threadIdx.x >> 6)] = 0; // empty survivor queue
     }
     __syncthreads();
 
@@ -832,13 +764,9 @@ __global__ __launch_bounds__(1024) void seed_filter_packed_kernel(const filter_p
             }
             filter_words<S, NWD, HV, 4, true, KM>(P, w, prev, nv, base0 + ch * 4096, lane, lds, idx_mask);
         }
-        if constexpr (S <= 2) {
-            if (P.queue_cap != 0)
-                drain_survivors<S>(P, lane, lds);
-        }
         sp += n_waves;
     }
-    cand_close(P, cand_chunk_of(P, lds), lane);
+    surv_close(P, cand_chunk_of(P, lds), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -852,23 +780,24 @@ struct verify_params
     uint64_t scan_begin; // owned: last symbol index in [scan_begin, scan_end)
     uint64_t scan_end;
     uint64_t pos_offset;
-    const candidate *cand;
-    const unsigned long long *counters; // [1] candidates
-    uint64_t cand_cap;
+    const band_rec *bands;
+    const unsigned long long *counters; // [3] band slots drawn
+    uint64_t band_cap;
+    unsigned long long *band_keys;      // band table (reset slot by slot as the bands are consumed)
+    unsigned long long *band_val;       // overlapping bands: seed hits counted; else: bit mask of the diagonals hit
+    const uint8_t *surplus; // per needle: seed hits a band needs (seeds - k); nullptr = 1 for every needle
+    uint32_t Bw;            // diagonals per band
+    uint32_t overlap;       // 1: bands extend k + 1 diagonals into the next one (sets with surplus seeds)
+    uint32_t max_m;         // diagonals are counted from max_m before the haystack's first symbol
     const uint32_t *peq32; // the brute table: [group][sigma+1][nw_table][64], needles top-aligned
     uint32_t sigma;        // alphabet size; LDS holds sigma+1 rows per thread (row sigma = no match)
     uint32_t nw_table;     // words per needle in that table
     uint32_t max_k;        // largest k of the set: 2*max_k + 1 end-position slots per candidate
-    uint32_t key_len;      // symbols per key (a key window must lie inside one segment)
     const int32_t *m;      // per pattern
     const int32_t *k;
     uint32_t report_begin; // 1: exact matchers report begin = end - m
-    uint32_t max_span;     // merged candidates: extra end positions a diagonal band answers for (0: none merged)
-    uint32_t cand_counter; // index of the candidate count in `counters` (1: raw candidates, 3: merged bands)
+    uint32_t max_span;     // diagonals of a band beyond the first: Bw - 1 (+ max_k + 1 with overlap)
     uint32_t wave_text;    // wave-per-candidate kernel: bytes of LDS per group for the candidate's text window
-    const uint8_t *needle_ranks;    // whole-seed check: the needles' symbols back to back (nullptr: check disabled)
-    const uint32_t *needle_offsets; // start of every needle in needle_ranks
-    uint32_t text_sigma;
     unsigned long long *seen; // hash set of (pattern << 40 | end)
     uint32_t seen_mask;
     spm_hit *hits;
@@ -881,29 +810,555 @@ struct verify_params
                                   // are wanted (journaled-sequence contexts: the symbols before it are left context)
 };
 
-// A candidate says: the key window at needle offset x matches the text at t.  The pigeonhole argument needs a seed that
-// occurs in the text UNCHANGED, and such a seed yields a candidate of its own -- so a candidate whose whole seed does
-// not match exactly can be dropped without losing an occurrence.  On long texts most candidates are chance matches of
-// the 16-symbol key (C4: 800 000 of 1 140 000; C3: 16 000 of 20 000); they fail this check after ~1.3 symbols.
-__device__ __forceinline__ bool seed_intact(const verify_params &P, const candidate &c, int64_t hay_b, int64_t hay_e)
+// ---------------------------------------------------------------------------------------------------
+// resolve: survivors -> (needle, offset) through the exact key table -> whole-seed check -> diagonal bands
+// ---------------------------------------------------------------------------------------------------
+// One lane per survivor, a full grid: the L2 round trips of the table probes overlap across thousands of waves instead of
+// stalling the streaming kernel.
+//   * A survivor says: the key window at needle offset x matches the text at t.  The pigeonhole argument needs a seed
+//     that occurs in the text UNCHANGED, and such a seed yields a survivor of its own -- so a (survivor, entry) pair whose
+//     whole seed does not match exactly is dropped without losing an occurrence.  On long texts most pairs are chance
+//     matches of the key (C4: 800 000 of 1 140 000; C3: 16 000 of 20 000); they fail after ~1.3 symbols.
+//   * What is left is counted into a hash table keyed (needle, haystack, diagonal band); the first arrival of a band
+//     appends it to the band list.  A band is verified ONCE, over every end position its diagonals can produce -- the 17
+//     sampled windows of one needle inside one 136-base microsatellite are one or two verifications, not 17; the 65
+//     seeds of a |P| = 1024, k = 64 occurrence one, not 65.
+//   * Sets whose needles carry k + 2 seeds (k >= kMergeMinK): an occurrence keeps >= 2 seeds intact, on diagonals <= k
+//     apart; bands overlap by k + 1 diagonals so that those seeds always share a band, and a band is verified only if it
+//     collected as many seed hits as the needle has surplus seeds.
+struct resolve_params
 {
-    if (!P.needle_ranks || c.pad != 0)
-        return true; // (a candidate with a diagonal range stands for several offsets of a periodic seed: kept)
-    const uint32_t pat = c.val >> 11, x = c.val & 0x7FF;
+    const survivor *surv;
+    unsigned long long *counters; // [1] survivor slots drawn (this pass), [3] band slots drawn, [5] candidates (stat),
+                                  // [8] survivors over all passes, [9] largest survivor demand of a pass, [2] overflow
+    uint64_t surv_cap;
+    const pass_entry *passes; // exact key tables, one per pass
+    uint32_t key_len;
+    uint32_t flank_check;     // 1: dna4 set without surplus seeds: seed signatures are checked against the packed text
+    uint32_t pieces_check;    // 1: ... and the piece count (see pieces_plausible)
+    const uint8_t *text;
+    uint64_t text_alloc;            // readable bytes from text
+    const uint8_t *needle_ranks;    // the needles' symbols back to back, padded (nullptr: no whole-seed check)
+    const uint32_t *needle_offsets; // start of every needle in needle_ranks
+    const int32_t *m, *k;
+    uint64_t hay_begin, hay_end;    // unsegmented scans: the haystack
+    const uint64_t *seg_offsets;
+    uint64_t n_segments;
+    uint32_t Bw, overlap, max_m;
+    uint32_t band_bits;             // key = pattern << 43 | segment << band_bits | band
+    unsigned long long *band_keys;
+    unsigned long long *band_val; // overlapping bands: seed-hit count; else: bit d set = a seed hit on diagonal d of the band
+    uint32_t table_mask;
+    band_rec *bands;
+    uint64_t band_cap;
+};
+
+// 16 bytes from an arbitrary address with ONE load: gfx950 under amdhsa runs with unaligned access enabled, so an
+// align-1 copy of 16 bytes is a single global_load_dwordx4.  (Byte loads would cost the memory pipe 16 instructions, each
+// as expensive as this one; the checks below run for 10^7..10^8 (survivor, entry) pairs on a repeat-rich text.)
+__device__ __forceinline__ uint4 load_bytes16(const uint8_t *p)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// the same near the end of a buffer: bytes at or beyond `limit` read as 0xFF (never equal to a symbol)
+__device__ __forceinline__ uint4 load_bytes16_guarded(const uint8_t *base, uint64_t idx, uint64_t limit)
+{
+    if (idx + 16 <= limit)
+        return load_bytes16(base + idx);
+    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int b = 0; b < 16; ++b)
+        if (idx + b < limit)
+            w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)base[idx + b] << (8 * (b & 3)));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t diff16(const uint4 a, const uint4 b, uint32_t n) // n <= 16 leading bytes compared
+{
+    const uint32_t d[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t have = n > 4 * i ? n - 4 * i : 0; // bytes of this dword that count
+        const uint32_t mask = have >= 4 ? 0xFFFFFFFFu : (have == 0 ? 0u : (1u << (8 * have)) - 1);
+        r |= d[i] & mask;
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t, uint32_t val, int64_t hay_b, int64_t hay_e)
+{
+    if (!P.needle_ranks)
+        return true;
+    const uint32_t pat = val >> 11, x = val & 0x7FF;
     const seed_plan sp = plan_seeds((uint32_t)P.m[pat], (uint32_t)P.k[pat]);
     const uint32_t o = (x / sp.q) * sp.q; // start of the seed inside the needle
-    const int64_t ts = (int64_t)c.t - (int64_t)(x - o); // where the seed would start in the text
+    const int64_t ts = (int64_t)t - (int64_t)(x - o); // where the seed would start in the text
     if (ts < hay_b || ts + (int64_t)sp.q > hay_e)
         return false; // it would stick out of the haystack
-    const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat] + o;
-    const uint8_t *tx = P.text + ts;
-    const uint32_t w0 = x - o, w1 = w0 + P.key_len; // the key window itself already matched
-    for (uint32_t i = 0; i < sp.q; ++i) {
-        if (i >= w0 && i < w1)
-            continue;
-        if (tx[i] != nd[i])
+    const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat] + o; // (the needle buffer is padded: no guard)
+    // (the key window itself already matched; comparing it again costs less than skipping it.)  16 symbols per round: a
+    // chance match of the key fails in the first
+    for (uint32_t i = 0; i < sp.q; i += 16) {
+        const uint32_t n = sp.q - i < 16 ? sp.q - i : 16;
+        if (diff16(load_bytes16_guarded(P.text, (uint64_t)ts + i, P.text_alloc), load_bytes16(nd + i), n))
             return false;
     }
+    return true;
+}
+
+// Piece count (dna4 sets without surplus seeds, i.e. k < kMergeMinK) -- the q-gram lemma on aligned pieces.  The seed
+// sits unchanged on diagonal d (needle position y <-> text index d + y).  Cut the needle into pieces of 8 symbols: an
+// occurrence with <= k edits leaves all but k of them unchanged, each displaced by at most k from its place on the
+// diagonal (the indels between it and the seed).  So if more than k pieces are found nowhere within +-k of their place,
+// no occurrence contains this seed here -- and an occurrence always has an intact seed whose pieces pass.  What this
+// removes: the seed hits of needles that merely END in a microsatellite or a poly-A run, in every stretch of the same
+// unit (their unique part fails after two or three blocks); each would have cost a band and a verification of ~170
+// columns.  Needles that ARE a repeat pass, as they must: they occur there.  A pair whose needle would stick out of the
+// haystack is not checked.
+__device__ __forceinline__ bool pieces_plausible(const resolve_params &P, uint64_t t, uint32_t val, int64_t hay_b, int64_t hay_e)
+{
+    if (!P.pieces_check)
+        return true;
+    const uint32_t pat = val >> 11, x = val & 0x7FF;
+    const uint32_t m = (uint32_t)P.m[pat], k = (uint32_t)P.k[pat];
+    if (k == 0 || k > 7 || m < 32)
+        return true;
+    const int64_t d = (int64_t)t - (int64_t)x;
+    if (d - (int64_t)k < hay_b || d + (int64_t)(m + k) > hay_e)
+        return true;
+    const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat]; // (padded: whole 16-byte loads)
+    uint32_t missing = 0;
+    for (uint32_t y = 0; y + 16 <= m; y += 16) { // two pieces per 16 needle symbols
+        const uint32_t two = pack16(load_bytes16(nd + y));
+        // text [d + y - k, d + y + 16 + k): 16 + 2k <= 30 symbols
+        const uint64_t w0 = (uint64_t)(d + (int64_t)y - (int64_t)k);
+        const uint64_t win = (uint64_t)pack16(load_bytes16_guarded(P.text, w0, P.text_alloc)) |
+                             ((uint64_t)pack16(load_bytes16_guarded(P.text, w0 + 16, P.text_alloc)) << 32);
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            const uint32_t piece = (two >> (16 * j)) & 0xFFFFu;
+            bool found = false;
+            for (uint32_t sh = 0; sh <= 2 * k; ++sh) // displacement sh - k
+                found = found || (((uint32_t)(win >> (2 * (8 * j + sh))) & 0xFFFFu) == piece);
+            missing += found ? 0u : 1u;
+        }
+        if (missing > k)
+            return false;
+    }
+    return true;
+}
+
+// Range code of an exact-table entry (.w):
+//   kRngSingle | r | ns << 4 [| kRngWhole]
+//                 the key sits at this one offset of the needle; its window starts r symbols into its seed; .z = signature:
+//                 the first ns (<= 16) symbols of the rest of the seed; kRngWhole: that IS the whole rest
+//   kRngRun | span
+//                 MANY offsets of the needle share the key (the needle IS a repeat there): no per-offset checks -- they
+//                 would pass wherever the text carries the same repeat --, one pair counted into the bands of the
+//                 diagonals t - offset - span .. t - offset
+constexpr uint32_t kRngRun = 0x8000u;
+constexpr uint32_t kRngSingle = 0x2000u;
+constexpr uint32_t kRngWhole = 0x1000u;
+constexpr uint32_t kSeedChecked = 0x4000u; // (queue only) the signature already showed the whole seed in the text
+
+// The 64 text symbols around a survivor's key window, [t - 16, t + 48), 2 bits each: every entry of the key is checked
+// against them in registers ("does the REST of the seed match too?") instead of with loads per entry -- 73 % of the
+// (survivor, entry) pairs of a repeat-rich text die here.
+struct text64
+{
+    uint64_t lo, hi; // symbols 0..31, 32..63
+    bool ok;         // false: the window is not wholly inside the haystack (no signature check then)
+};
+
+__device__ __forceinline__ uint32_t syms16(const text64 &W, uint32_t first) // 16 symbols from index `first` (<= 48)
+{
+    if (first >= 32)
+        return (uint32_t)(W.hi >> (2 * (first - 32)));
+    return (uint32_t)(W.lo >> (2 * first)) | (first ? (uint32_t)(W.hi << (2 * (32 - first)) ) : 0u);
+}
+
+// the first n (<= 16) symbols of the seed's rest -- r before the key window, then those after it -- against the text
+__device__ __forceinline__ bool seed_sig_ok(const text64 &W, uint32_t sig, uint32_t r, uint32_t n, uint32_t H)
+{
+    if (n == 0)
+        return true;
+    const uint32_t nl = r < n ? r : n; // symbols taken from before the window: text [t - r, t - r + nl)
+    uint32_t got = nl ? syms16(W, 16 - r) : 0u;
+    if (nl < 16) {
+        got &= (1u << (2 * nl)) - 1;
+        got |= syms16(W, 16 + H) << (2 * nl);
+    }
+    const uint32_t mask = n >= 16 ? 0xFFFFFFFFu : ((1u << (2 * n)) - 1);
+    return ((got ^ sig) & mask) == 0;
+}
+
+// (survivor, entry, offset) pairs wait in LDS until a wave has 64 of them: a key shared by twenty needles, or by eight
+// offsets of one, would otherwise keep one lane busy with checks while 63 idle
+constexpr uint32_t kPairCap = 128;
+struct pair_queue // per wave
+{
+    uint32_t t_lo[kPairCap], t_hi[kPairCap], val[kPairCap], rng[kPairCap], seg[kPairCap];
+};
+
+struct band_chunk // this wave's chunk of the band list (wave-uniform registers)
+{
+    uint64_t base;
+    uint32_t used, size, draws;
+};
+// The first draws of a wave take exactly what it needs, so a scan with few bands (the usual case; and the long-needle
+// sets whose wave-per-band verification wants every wave busy) leaves a dense list; later draws take growing chunks.
+constexpr uint32_t kDenseDraws = 4;
+
+// 64 (or the last few) pairs, one per lane: checks, then the bands they count into
+__device__ __forceinline__ void resolve_pairs(const resolve_params &R, const pair_queue &Q, uint32_t first, uint32_t n,
+                                              uint32_t lane, band_chunk &C, uint32_t &n_cand)
+{
+    bool emit = lane < n;
+    uint64_t t = 0, seg = 0;
+    uint32_t val = 0, rng = 0;
+    int64_t sb = (int64_t)R.hay_begin, se = (int64_t)R.hay_end;
+    if (emit) {
+        const uint32_t i = first + lane;
+        t = ((uint64_t)Q.t_hi[i] << 32) | Q.t_lo[i];
+        val = Q.val[i];
+        rng = Q.rng[i];
+        seg = Q.seg[i];
+        if (R.seg_offsets) {
+            sb = (int64_t)R.seg_offsets[seg];
+            se = (int64_t)R.seg_offsets[seg + 1];
+        }
+    }
+    if (emit && !(rng & kRngRun) &&
+        !(((rng & kSeedChecked) || seed_intact(R, t, val, sb, se)) && pieces_plausible(R, t, val, sb, se)))
+        emit = false;
+    // bands this pair counts into: those holding a diagonal of [d_lo, d_hi]; with overlapping bands also the one
+    // before, if d_lo still lies in its k-wide extension
+    uint32_t pat = 0;
+    int64_t b_cur = 0, b_last = -1, d_lo = 0, d_hi = 0;
+    if (emit) {
+        ++n_cand;
+        pat = val >> 11;
+        d_hi = (int64_t)t - (int64_t)(val & 0x7FF) - sb + (int64_t)R.max_m;
+        d_lo = d_hi - (int64_t)(rng & 0x7FF);
+        b_cur = d_lo / (int64_t)R.Bw;
+        b_last = d_hi / (int64_t)R.Bw;
+        if (R.overlap && b_cur > 0 && d_lo - b_cur * (int64_t)R.Bw <= (int64_t)R.k[pat])
+            --b_cur;
+    }
+    while (__ballot(b_cur <= b_last) != 0) {
+        bool claimed = false;
+        uint32_t bslot = 0;
+        if (b_cur <= b_last && (uint64_t)b_cur >> R.band_bits) {
+            atomicAdd(&R.counters[2], 1ull); // a haystack too long for the key layout: the host falls back
+            b_cur = b_last + 1;
+        }
+        if (b_cur <= b_last) {
+            const unsigned long long bkey =
+                ((unsigned long long)pat << 43) | ((unsigned long long)seg << R.band_bits) | (unsigned long long)b_cur;
+            uint32_t s2 = (uint32_t)mix64(bkey) & R.table_mask;
+            bool placed = false;
+            for (uint32_t tries = 0; tries < 8192 && !placed; ++tries) {
+                const unsigned long long o = atomicCAS(&R.band_keys[s2], kBandEmpty, bkey);
+                if (o == kBandEmpty) {
+                    claimed = true;
+                    placed = true;
+                } else if (o == bkey) {
+                    placed = true;
+                } else {
+                    s2 = (s2 + 1) & R.table_mask;
+                }
+            }
+            if (placed) {
+                if (R.overlap) {
+                    atomicAdd(&R.band_val[s2], 1ull);
+                } else { // which diagonals of the band (Bw <= 64) are hit: the verification covers just those
+                    const int64_t b0 = b_cur * (int64_t)R.Bw;
+                    const uint32_t o_lo = (uint32_t)(d_lo > b0 ? d_lo - b0 : 0);
+                    const uint32_t o_hi = (uint32_t)(d_hi < b0 + (int64_t)R.Bw - 1 ? d_hi - b0 : (int64_t)R.Bw - 1);
+                    const unsigned long long run = o_hi - o_lo >= 63 ? ~0ull : ((1ull << (o_hi - o_lo + 1)) - 1);
+                    atomicOr(&R.band_val[s2], run << o_lo);
+                }
+            } else {
+                atomicAdd(&R.counters[2], 1ull); // table full: the host starts over with more room
+            }
+            bslot = s2;
+        }
+        const uint64_t mm = __ballot(claimed);
+        if (mm != 0) {
+            const uint32_t nn = __popcll(mm);
+            if (C.used + nn > C.size) { // close this chunk (unused tail invalid), draw the next
+                for (uint32_t q = C.used + lane; q < C.size; q += 64)
+                    if (C.base + q < R.band_cap)
+                        R.bands[C.base + q].val = kBandInvalid;
+                uint32_t next = C.size * 2 < kChunkMin ? kChunkMin : (C.size * 2 > kChunkMax ? kChunkMax : C.size * 2);
+                next = next < nn ? nn : next;
+                if (C.draws < kDenseDraws) {
+                    next = nn;
+                    ++C.draws;
+                }
+                unsigned long long b = 0;
+                if (lane == 0)
+                    b = atomicAdd(&R.counters[3], (unsigned long long)next);
+                C.base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+                C.used = 0;
+                C.size = next;
+            }
+            if (claimed) {
+                const uint64_t idx = C.base + C.used + __popcll(mm & ((1ull << lane) - 1));
+                if (idx < R.band_cap) {
+                    band_rec br;
+                    br.slot = bslot;
+                    br.val = pat << 11;
+                    br.seg = (uint32_t)seg;
+                    br.band = (uint32_t)b_cur;
+                    R.bands[idx] = br;
+                } else {
+                    atomicAdd(&R.counters[2], 1ull); // band list full
+                }
+            }
+            C.used += nn;
+        }
+        ++b_cur;
+    }
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
+{
+    __shared__ pair_queue queues[4];
+    unsigned long long n = R.counters[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&R.counters[8], n);
+        atomicMax(&R.counters[9], n);
+    }
+    if (n > R.surv_cap)
+        n = R.surv_cap;
+    const uint32_t lane = threadIdx.x & 63;
+    pair_queue &Q = queues[threadIdx.x >> 6];
+    uint32_t qn = 0; // pairs waiting (wave-uniform)
+    band_chunk C;
+    C.base = 0;
+    C.used = 0;
+    C.size = 0;
+    C.draws = 0;
+    uint32_t n_cand = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride; // wave-uniform trip count: the queue and the appends are wave-collective
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool probing = false;
+        uint32_t key = 0;
+        uint64_t t = 0, seg = 0;
+        pass_entry T = R.passes[0];
+        if (i < n) {
+            const survivor sv = R.surv[i];
+            if (sv.t_hi != kSurvInvalid) {
+                probing = true;
+                key = sv.key;
+                t = ((uint64_t)sv.t_hi << 32) | sv.t_lo;
+                if (sv.pad != 0)
+                    T = R.passes[sv.pad];
+            }
+        }
+        if (probing && R.seg_offsets) {
+            uint64_t lo = 0, hi = R.n_segments; // invariant: seg_offsets[lo] <= t < seg_offsets[hi]
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (R.seg_offsets[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            seg = lo;
+            if ((int64_t)t + (int64_t)R.key_len > (int64_t)R.seg_offsets[lo + 1])
+                probing = false; // the key window straddles two haystacks
+        }
+        // the text around the key window, once per survivor
+        text64 W;
+        W.lo = 0;
+        W.hi = 0;
+        W.ok = false;
+        if (probing && R.flank_check) { // (dna4 sets: 2-bit codes)
+            int64_t sb = (int64_t)R.hay_begin, se = (int64_t)R.hay_end;
+            if (R.seg_offsets) {
+                sb = (int64_t)R.seg_offsets[seg];
+                se = (int64_t)R.seg_offsets[seg + 1];
+            }
+            if ((int64_t)t - 16 >= sb && (int64_t)t + 48 <= se && t + 48 <= R.text_alloc) {
+                const uint8_t *p = R.text + (t - 16);
+                W.lo = (uint64_t)pack16(load_bytes16(p)) | ((uint64_t)pack16(load_bytes16(p + 16)) << 32);
+                W.hi = (uint64_t)pack16(load_bytes16(p + 32)) | ((uint64_t)pack16(load_bytes16(p + 48)) << 32);
+                W.ok = true;
+            }
+        }
+        uint32_t slot = ht_hash(key) & T.ht_mask;
+        while (__ballot(probing) != 0) {
+            // the probe sequence four slots at a time: one aligned 64-byte line, its four loads in flight together, so a
+            // key that twenty needles share costs five round trips to L2 instead of twenty
+            uint4 e4[4];
+            const uint32_t g0 = slot & ~3u;
+            if (probing) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    e4[j] = T.ht[g0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t val = 0, rng = 0;
+                bool have = false;
+                if (probing && g0 + j >= slot) {
+                    const uint4 e = e4[j];
+                    if (e.y == kHtEmpty) {
+                        probing = false;
+                    } else if (e.x == key) {
+                        have = true;
+                        val = e.y;
+                        rng = e.w;
+                        if (!(rng & kRngRun)) {
+                            const uint32_t r0 = rng & 0xF, ns = (rng >> 4) & 0x1F;
+                            const bool whole = (rng & kRngWhole) != 0;
+                            rng = 0;
+                            if (W.ok) { // does the rest of the seed match?  (registers only)
+                                if (!seed_sig_ok(W, e.z, r0, ns, R.key_len))
+                                    have = false;
+                                else if (whole)
+                                    rng = kSeedChecked;
+                            }
+                        }
+                    }
+                }
+                // queue the pairs of this step; 64 waiting pairs are resolved at once
+                const uint64_t mm = __ballot(have);
+                if (mm != 0) {
+                    if (have) {
+                        const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
+                        Q.t_lo[q] = (uint32_t)t;
+                        Q.t_hi[q] = (uint32_t)(t >> 32);
+                        Q.val[q] = val;
+                        Q.rng[q] = rng;
+                        Q.seg[q] = (uint32_t)seg;
+                    }
+                    qn += __popcll(mm);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (qn >= 64) {
+                        qn -= 64;
+                        resolve_pairs(R, Q, qn, 64, lane, C, n_cand);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            slot = (g0 + 4) & T.ht_mask;
+        }
+    }
+    if (qn != 0)
+        resolve_pairs(R, Q, 0, qn, lane, C, n_cand);
+    for (uint32_t q = C.used + lane; q < C.size; q += 64)
+        if (C.base + q < R.band_cap)
+            R.bands[C.base + q].val = kBandInvalid;
+    wave_count_add(R.counters + 5, n_cand);
+}
+
+// Reserve hit slots for a whole wave with ONE atomic: lane l gets `mine` consecutive slots starting at the returned index.
+// (One atomic per end-position slot and wave, as the brute-force kernels do it, serialises on the counter's address at
+// ~100/us: a repeat-rich text reports millions of hits.)  Call with the wave converged.
+__device__ __forceinline__ unsigned long long wave_reserve_hits(unsigned long long *counter, uint32_t mine)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o)
+            incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    unsigned long long base = 0;
+    if (total != 0) {
+        if (lane == 0)
+            base = atomicAdd(counter, (unsigned long long)total);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+    }
+    return base + (incl - mine);
+}
+
+// one key per reported hit in the scan's dedupe set; true if this is the first report of (pattern, end)
+__device__ __forceinline__ bool seen_insert(const verify_params &P, uint32_t pat, int64_t e)
+{
+    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
+    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
+    // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means more hits than
+    // it was sized for: flag it, the host starts over with a larger one
+    for (uint32_t tries = 0; tries < 512; ++tries) {
+        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
+        if (old == ~0ull)
+            return true;
+        if (old == key)
+            return false;
+        slot = (slot + 1) & P.seen_mask;
+    }
+    atomicAdd(P.overflow, 1ull);
+    return false;
+}
+
+// What a band record stands for (verification side).  Returns false if the band has too few seed hits, lies outside the
+// owned range, or is an unused list slot.  Consumes the band's table slot (the table is empty again after the scan).
+struct band_geom
+{
+    uint32_t pat;
+    int64_t m, k;
+    int64_t e_lo, e_hi; // exclusive end positions it answers for
+    int64_t ws;         // cold start
+};
+
+__device__ __forceinline__ bool decode_band(const verify_params &P, const band_rec &c, bool consume, band_geom &g)
+{
+    if (c.val == kBandInvalid)
+        return false;
+    g.pat = c.val >> 11;
+    const unsigned long long v = P.band_val[c.slot];
+    if (consume) {
+        P.band_val[c.slot] = 0;
+        P.band_keys[c.slot] = kBandEmpty;
+    }
+    if (P.overlap ? (uint32_t)v < (P.surplus ? (uint32_t)P.surplus[g.pat] : 1u) : v == 0)
+        return false;
+    g.m = P.m[g.pat];
+    g.k = P.k[g.pat];
+    int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
+    if (P.seg_offsets) { // every segment is a haystack of its own
+        const int64_t sb = (int64_t)P.seg_offsets[c.seg], se = (int64_t)P.seg_offsets[c.seg + 1];
+        own_b = P.seg_owned ? sb + (int64_t)P.seg_owned[c.seg] : sb;
+        own_e = se;
+        hay_b = sb;
+    }
+    // diagonals d .. d + span: needle position 0 <-> text index d.  Bands that do not overlap know which of their
+    // diagonals were hit: an isolated seed hit is verified over its own diagonal, a repeat stretch over the whole band
+    int64_t d = hay_b - (int64_t)P.max_m + (int64_t)c.band * (int64_t)P.Bw;
+    int64_t span = (int64_t)P.Bw - 1 + (P.overlap ? g.k + 1 : 0);
+    if (!P.overlap) {
+        const int lo = __ffsll((long long)v) - 1, hi = 63 - __clzll((long long)v);
+        d += lo;
+        span = hi - lo;
+    }
+    g.e_lo = d + g.m - g.k;
+    g.e_hi = d + g.m + g.k + span;
+    // ownership: last symbol e-1 in [own_b, own_e)
+    if (g.e_lo < own_b + 1)
+        g.e_lo = own_b + 1;
+    if (g.e_hi > own_e)
+        g.e_hi = own_e;
+    if (g.e_lo > g.e_hi)
+        return false;
+    // cold start m+k symbols before the first end position (or at the haystack start)
+    g.ws = g.e_lo - (g.m + g.k);
+    if (g.ws < hay_b)
+        g.ws = hay_b;
     return true;
 }
 
@@ -923,68 +1378,35 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
     const uint32_t n_slots = 2 * P.max_k + 1 + P.max_span;
     for (uint32_t r = 0; r < n_slots; ++r)
         hitbuf[(size_t)r * nthr + tid] = 0;
-    unsigned long long n_cand = P.counters[P.cand_counter];
-    if (n_cand > P.cand_cap)
-        n_cand = P.cand_cap; // overflow is handled by the host (brute-force re-run)
+    unsigned long long n_cand = P.counters[3];
+    if (n_cand > P.band_cap)
+        n_cand = P.band_cap; // overflow is handled by the host
     const uint64_t stride = (uint64_t)gridDim.x * nthr;
     uint32_t n_valid = 0;
-    for (uint64_t ci = (uint64_t)blockIdx.x * nthr + tid; ci < n_cand; ci += stride) {
-        const candidate c = P.cand[ci];
-        if (c.val == kCandInvalid)
-            continue; // a slot its wave reserved but did not fill
-        ++n_valid;
-        const uint32_t pat = c.val >> 11;
-        const bool merged = (c.pad & kCandMerged) != 0;
-        // raw candidate: diagonals t - x - r .. t - x (r = c.pad);  merged band: diagonals t .. t + span
-        const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF) + (int64_t)c.pad;
-        const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : (int64_t)c.pad;
-        const int64_t m = P.m[pat];
-        const int64_t k = P.k[pat];
-        const int64_t d = (int64_t)c.t - x; // first diagonal: needle position 0 <-> text index d
-        // exclusive end positions this candidate answers for: e in [d+m-k, d+span+m+k]
-        int64_t e_lo = d + m - k;
-        int64_t e_hi = d + m + k + span;
-        // ownership: last symbol e-1 in [scan_begin, scan_end)
-        int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
-        if (P.seg_offsets) {
-            // every segment is a haystack of its own: find the one holding the key window, clamp to it
-            uint64_t lo = 0, hi = P.n_segments; // invariant: seg_offsets[lo] <= t < seg_offsets[hi]
-            if (merged) {
-                lo = (c.pad & ~kCandMerged) - 1;
-            } else {
-                while (hi - lo > 1) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (P.seg_offsets[mid] <= c.t)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-            }
-            const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
-            if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
-                continue; // the key window straddles two haystacks
-            own_b = P.seg_owned ? sb + (int64_t)P.seg_owned[lo] : sb;
-            own_e = se;
-            hay_b = sb;
-        }
-        if (!merged && !seed_intact(P, c, hay_b, own_e))
-            continue;
-        if (e_lo < own_b + 1)
-            e_lo = own_b + 1;
-        if (e_hi > own_e)
-            e_hi = own_e;
-        if (e_lo > e_hi)
-            continue;
-        // cold start m+k symbols before the first end position (or at the haystack start)
-        int64_t ws = e_lo - (m + k);
-        if (ws < hay_b)
-            ws = hay_b;
+    // wave-uniform trip count (the emission below is wave-collective); a lane without a band idles through the round
+    const uint64_t rounds = (n_cand + stride - 1) / stride;
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        const uint64_t ci = rd * stride + (uint64_t)blockIdx.x * nthr + tid;
+        band_geom g;
+        g.pat = 0;
+        g.m = 1;
+        g.k = 0;
+        g.e_lo = 0;
+        g.e_hi = -1;
+        g.ws = 0;
+        // (false: an unused list slot, too few seed hits, or nothing owned)
+        const bool active = ci < n_cand && decode_band(P, P.bands[ci], true, g);
+        if (active)
+            ++n_valid;
+        const uint32_t pat = g.pat;
+        const int64_t m = g.m, k = g.k, e_lo = g.e_lo, e_hi = active ? g.e_hi : g.ws, ws = g.ws;
         // stage this needle's rows: brute table [group][row][word][lane], top NWN words
         const uint32_t *src = P.peq32 + (((size_t)(pat >> 6) * rows) * P.nw_table + (P.nw_table - NWN)) * 64 + (pat & 63);
-        for (uint32_t r = 0; r < rows; ++r)
+        if (active)
+            for (uint32_t r = 0; r < rows; ++r)
 #pragma unroll
-            for (int w = 0; w < NWN; ++w)
-                vlds[((size_t)r * NWN + w) * nthr + tid] = src[((size_t)r * P.nw_table + w) * 64];
+                for (int w = 0; w < NWN; ++w)
+                    vlds[((size_t)r * NWN + w) * nthr + tid] = src[((size_t)r * P.nw_table + w) * 64];
         bool any_hit = false;
         myers_lane<NWN, false> L;
         {
@@ -998,7 +1420,9 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
             L.score = (int32_t)m;
         }
         const int64_t blk0 = ws & ~15ll;
-        uint4 nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (active)
+            nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
         for (int64_t blk = blk0; blk < e_hi; blk += 16) {
             const uint4 cur = nxt;
             if (blk + 16 < e_hi)
@@ -1024,43 +1448,38 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         }
         // ---- deferred emission: slot r = end position e_lo + r ----
         if (__ballot(any_hit) != 0) {
-            for (int64_t r = 0; r < (int64_t)n_slots; ++r) {
-                uint32_t sc1 = 0;
-                if (any_hit && r <= e_hi - e_lo) {
-                    sc1 = hitbuf[(size_t)r * nthr + tid];
-                    hitbuf[(size_t)r * nthr + tid] = 0;
-                }
-                bool fresh = false;
-                const int64_t e = e_lo + r;
+            const int32_t nr = any_hit ? (int32_t)(e_hi - e_lo) + 1 : 0;
+            // pass 1: dedupe across the seeds / bands of one occurrence; what stays in the slots is new
+            uint32_t fresh = 0;
+            for (int32_t r = 0; r < nr; ++r) {
+                const uint32_t sc1 = hitbuf[(size_t)r * nthr + tid];
                 if (sc1) {
-                    // dedupe across the seeds of one occurrence
-                    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
-                    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-                    // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means
-                    // more hits than the caller's buffer takes: flag it, the host re-runs with the brute engine
-                    bool placed = false;
-                    for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
-                        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
-                        if (old == ~0ull) {
-                            fresh = true;
-                            placed = true;
-                        } else if (old == key) {
-                            placed = true;
-                        } else {
-                            slot = (slot + 1) & P.seen_mask;
-                        }
-                    }
-                    if (!placed)
-                        atomicAdd(P.overflow, 1ull);
+                    if (seen_insert(P, pat, e_lo + r))
+                        ++fresh;
+                    else
+                        hitbuf[(size_t)r * nthr + tid] = 0;
                 }
-                if (__ballot(fresh) != 0)
-                    wave_append_hits(fresh, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
-                                     (int32_t)sc1 - 1, P.hits, P.hit_counter, P.hit_cap);
+            }
+            // pass 2: one reservation for the wave, then every lane writes its run
+            unsigned long long idx = wave_reserve_hits(P.hit_counter, fresh);
+            for (int32_t r = 0; r < nr; ++r) {
+                const uint32_t sc1 = hitbuf[(size_t)r * nthr + tid];
+                hitbuf[(size_t)r * nthr + tid] = 0;
+                if (sc1) {
+                    if (idx < P.hit_cap) {
+                        const int64_t e = e_lo + r;
+                        spm_hit h;
+                        h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
+                        h.pattern = pat;
+                        h.score = (int32_t)sc1 - 1;
+                        P.hits[idx] = h;
+                    }
+                    ++idx;
+                }
             }
         }
     }
-    if (P.cand_counter == 1) // raw candidates: how many reserved slots were real ones
-        wave_count_add(P.hit_counter + 5, n_valid);
+    wave_count_add(P.hit_counter + 7, n_valid); // bands verified
 }
 
 
@@ -1087,9 +1506,9 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
     uint8_t *tw = gbase + ((n_slots * 2 + 15) & ~15u);
     for (uint32_t r = gl; r < n_slots; r += G)
         hb[r] = 0;
-    unsigned long long n_cand = P.counters[P.cand_counter];
-    if (n_cand > P.cand_cap)
-        n_cand = P.cand_cap;
+    unsigned long long n_cand = P.counters[3];
+    if (n_cand > P.band_cap)
+        n_cand = P.band_cap;
     const uint64_t stride = (uint64_t)gridDim.x * waves * GPW;
     const uint32_t rows = P.sigma + 1;
     uint32_t n_valid = 0;
@@ -1098,56 +1517,34 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         bool active = ci < n_cand;
         uint32_t pat = 0;
         int64_t m = 1, k = 0, e_lo = 0, e_hi = -1, ws = 0;
-        candidate c;
-        c.val = kCandInvalid;
+        band_rec c;
+        c.val = kBandInvalid;
+        c.slot = 0;
         if (active)
-            c = P.cand[ci];
-        active = active && c.val != kCandInvalid;
+            c = P.bands[ci];
+        {
+            band_geom g;
+            g.pat = 0;
+            g.m = 1;
+            g.k = 0;
+            g.e_lo = 0;
+            g.e_hi = -1;
+            g.ws = 0;
+            active = active && decode_band(P, c, false, g); // every lane of the group reads the band's count ...
+            pat = g.pat;
+            m = g.m;
+            k = g.k;
+            e_lo = g.e_lo;
+            e_hi = g.e_hi;
+            ws = g.ws;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (gl == 0 && c.val != kBandInvalid) { // ... then one of them gives the table slot back
+            P.band_val[c.slot] = 0;
+            P.band_keys[c.slot] = kBandEmpty;
+        }
         if (active && gl == 0)
             ++n_valid;
-        if (active) {
-            pat = c.val >> 11;
-            const bool merged = (c.pad & kCandMerged) != 0;
-            const int64_t x = merged ? 0 : (int64_t)(c.val & 0x7FF) + (int64_t)c.pad;
-            const int64_t span = merged ? (int64_t)(c.val & 0x7FF) : (int64_t)c.pad;
-            m = P.m[pat];
-            k = P.k[pat];
-            const int64_t d = (int64_t)c.t - x;
-            e_lo = d + m - k;
-            e_hi = d + m + k + span;
-            int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
-            if (P.seg_offsets) {
-                uint64_t lo = 0, hi = P.n_segments;
-                if (merged) {
-                    lo = (c.pad & ~kCandMerged) - 1;
-                } else {
-                    while (hi - lo > 1) {
-                        const uint64_t mid = (lo + hi) >> 1;
-                        if (P.seg_offsets[mid] <= c.t)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                }
-                const int64_t sb = (int64_t)P.seg_offsets[lo], se = (int64_t)P.seg_offsets[lo + 1];
-                if (!merged && (int64_t)c.t + (int64_t)P.key_len > se)
-                    active = false;
-                own_b = P.seg_owned ? sb + (int64_t)P.seg_owned[lo] : sb;
-                own_e = se;
-                hay_b = sb;
-            }
-            if (!merged && !seed_intact(P, c, hay_b, own_e))
-                active = false;
-            if (e_lo < own_b + 1)
-                e_lo = own_b + 1;
-            if (e_hi > own_e)
-                e_hi = own_e;
-            if (e_lo > e_hi)
-                active = false;
-            ws = e_lo - (m + k);
-            if (ws < hay_b)
-                ws = hay_b;
-        }
         const uint32_t nb = (uint32_t)((m + 31) >> 5);        // blocks of this needle
         const bool is_last = gl + 1 == nb;
         const uint32_t out_bit = is_last ? (uint32_t)((m - 1) & 31) : 31u; // where this block's hout is read
@@ -1226,239 +1623,40 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (__ballot(any_hit) != 0) {
-            for (uint32_t r0 = 0; r0 < n_slots; r0 += G) {
-                const uint32_t r = r0 + gl;
-                uint32_t sc1 = 0;
-                if (active && r < n_slots && (int64_t)r <= e_hi - e_lo) {
-                    sc1 = hb[r];
-                    hb[r] = 0;
-                }
-                bool is_new = false;
-                const int64_t e = e_lo + r;
+            // pass 1: every lane of a group takes the slots r = gl, gl + G, ..: dedupe, keep what is new
+            const uint32_t nr = active ? (uint32_t)(e_hi - e_lo) + 1 : 0u;
+            uint32_t fresh = 0;
+            for (uint32_t r = gl; r < nr; r += G) {
+                const uint32_t sc1 = hb[r];
                 if (sc1) {
-                    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
-                    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-                    bool placed = false;
-                    for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
-                        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
-                        if (old == ~0ull) {
-                            is_new = true;
-                            placed = true;
-                        } else if (old == key) {
-                            placed = true;
-                        } else {
-                            slot = (slot + 1) & P.seen_mask;
-                        }
-                    }
-                    if (!placed)
-                        atomicAdd(P.overflow, 1ull);
+                    if (seen_insert(P, pat, e_lo + (int64_t)r))
+                        ++fresh;
+                    else
+                        hb[r] = 0;
                 }
-                if (__ballot(is_new) != 0)
-                    wave_append_hits(is_new, (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset, pat,
-                                     (int32_t)sc1 - 1, P.hits, P.hit_counter, P.hit_cap);
+            }
+            // pass 2: one reservation for the wave, then every lane writes its run
+            unsigned long long idx = wave_reserve_hits(P.hit_counter, fresh);
+            for (uint32_t r = gl; r < nr; r += G) {
+                const uint32_t sc1 = hb[r];
+                hb[r] = 0;
+                if (sc1) {
+                    if (idx < P.hit_cap) {
+                        const int64_t e = e_lo + (int64_t)r;
+                        spm_hit h;
+                        h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
+                        h.pattern = pat;
+                        h.score = (int32_t)sc1 - 1;
+                        P.hits[idx] = h;
+                    }
+                    ++idx;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (P.cand_counter == 1)
-        wave_count_add(P.hit_counter + 5, n_valid);
-}
-
-// ---- candidate compaction (needles with few errors) ----------------------------------------------------------------
-// One lane per candidate means a wave is as slow as its slowest lane, so dropping chance candidates inside the
-// verification kernel buys nothing while every wave still holds a true one.  This pass applies the whole-seed check
-// first and hands the verification a dense list of the survivors.
-__global__ void compact_candidates_kernel(const verify_params P, candidate *out, unsigned long long *out_count,
-                                          uint64_t out_cap)
-{
-    unsigned long long n = P.counters[1];
-    if (n > P.cand_cap)
-        n = P.cand_cap;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t n_valid = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (n + stride - 1) / stride; // wave-uniform trip count: the appends are wave-collective
-    for (uint64_t r = 0; r < rounds; ++r) {
-        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        bool keep = false;
-        candidate c;
-        c.t = 0;
-        c.val = kCandInvalid;
-        c.pad = 0;
-        if (i < n) {
-            c = P.cand[i];
-            keep = c.val != kCandInvalid;
-            n_valid += keep ? 1u : 0u;
-        }
-        if (keep) {
-            int64_t hay_b = (int64_t)P.ctx_begin, hay_e = (int64_t)P.scan_end;
-            if (P.seg_offsets) {
-                uint64_t lo = 0, hi = P.n_segments;
-                while (hi - lo > 1) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (P.seg_offsets[mid] <= c.t)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                hay_b = (int64_t)P.seg_offsets[lo];
-                hay_e = (int64_t)P.seg_offsets[lo + 1];
-                keep = (int64_t)c.t + (int64_t)P.key_len <= hay_e;
-            }
-            keep = keep && seed_intact(P, c, hay_b, hay_e);
-        }
-        const uint64_t m = __ballot(keep);
-        if (m != 0) {
-            unsigned long long base = 0;
-            const int leader = __ffsll((unsigned long long)m) - 1;
-            if ((int)lane == leader)
-                base = atomicAdd(out_count, (unsigned long long)__popcll(m));
-            base = __shfl(base, leader);
-            const uint64_t idx = base + __popcll(m & ((1ull << lane) - 1));
-            if (keep && idx < out_cap)
-                out[idx] = c;
-        }
-    }
-    wave_count_add(P.hit_counter + 5, n_valid);
-}
-
-// ---- candidate merging for large k ------------------------------------------------------------------------------
-// With k+1 seeds every occurrence is verified once per surviving seed (65 times for k = 64) and short keys let chance
-// matches through.  Needles with k >= kMergeMinK therefore carry k+2 seeds: an occurrence with <= k errors keeps >= 2 of
-// them intact, on diagonals at most k apart.  Candidates are counted per (needle, haystack, diagonal band); a band is
-// verified once, over every end position its diagonals can produce, if it collected as many seed hits as the needle
-// has surplus seeds (1 for needles that kept k+1 seeds).  Bands are Bw diagonals wide and overlap by k, so the intact
-// seeds of one occurrence always share a band.
-struct merge_params
-{
-    const candidate *cand;
-    const unsigned long long *counters; // [1] raw candidates
-    unsigned long long *out_count;      // counters[3]
-    uint64_t cand_cap;
-    const int32_t *m, *k;
-    const uint8_t *surplus; // per needle: seeds - k
-    uint32_t key_len, max_m, Bw, table_mask;
-    uint64_t hay_begin; // unsegmented scans: first symbol of the haystack
-    const uint64_t *seg_offsets;
-    uint64_t n_segments;
-    uint2 *aux;      // per candidate: {segment, primary band}; segment 0xFFFFFFFF = dropped
-    uint32_t *owner; // band table: (candidate << 1 | secondary) of the first arrival, 0xFFFFFFFF = empty
-    uint32_t *count; // seed hits per band
-    uint2 *own_slot; // per candidate: the table slots it claimed (primary, secondary band), 0xFFFFFFFF = none
-    const uint32_t *seg_owned; // optional (verify_params::seg_owned): bands that end before it are not verified
-    verify_params V;           // text, needles, scan range: the whole-seed check of every candidate
-    candidate *out;
-    uint64_t out_cap;
-};
-
-__global__ void merge_aux_kernel(const merge_params P)
-{
-    unsigned long long n = P.counters[1];
-    if (n > P.cand_cap)
-        n = P.cand_cap;
-    uint32_t n_valid = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const candidate c = P.cand[i];
-        n_valid += c.val != kCandInvalid ? 1u : 0u;
-        uint64_t seg = 0;
-        int64_t sb = (int64_t)P.hay_begin;
-        bool drop = c.val == kCandInvalid;
-        if (P.seg_offsets) {
-            uint64_t lo = 0, hi = P.n_segments;
-            while (hi - lo > 1) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (P.seg_offsets[mid] <= c.t)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            seg = lo;
-            sb = (int64_t)P.seg_offsets[lo];
-            drop = drop || (int64_t)c.t + (int64_t)P.key_len > (int64_t)P.seg_offsets[lo + 1];
-            if (!drop)
-                drop = !seed_intact(P.V, c, sb, (int64_t)P.seg_offsets[lo + 1]);
-        } else if (!drop) {
-            drop = !seed_intact(P.V, c, (int64_t)P.V.ctx_begin, (int64_t)P.V.scan_end);
-        }
-        // diagonal relative to the haystack, shifted so that it is never negative (t >= sb, offset <= max_m)
-        const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
-        P.aux[i] = drop ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2((uint32_t)seg, (uint32_t)(dr / (int64_t)P.Bw));
-    }
-    wave_count_add(P.out_count + 2, n_valid); // counters[5]
-}
-
-__global__ void merge_count_kernel(const merge_params P)
-{
-    unsigned long long n = P.counters[1];
-    if (n > P.cand_cap)
-        n = P.cand_cap;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint2 a = P.aux[i];
-        uint32_t claimed[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (a.x != 0xFFFFFFFFu) {
-            const candidate c = P.cand[i];
-            const uint32_t pat = c.val >> 11;
-            const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
-            const int64_t dr = (int64_t)c.t - (int64_t)(c.val & 0x7FF) - sb + (int64_t)P.max_m;
-            // band b covers diagonals [b*Bw, (b+1)*Bw + k]: the primary band, and the one before it if this diagonal
-            // still lies in its k-wide extension
-            const bool also_prev = a.y > 0 && dr - (int64_t)a.y * P.Bw <= (int64_t)P.k[pat];
-            for (uint32_t sec = 0; sec <= (also_prev ? 1u : 0u); ++sec) {
-                const uint32_t band = a.y - sec;
-                const uint32_t me = (uint32_t)(i << 1) | sec;
-                uint32_t s = (uint32_t)mix64(((uint64_t)pat << 40) ^ ((uint64_t)a.x << 17) ^ band) & P.table_mask;
-                while (true) {
-                    uint32_t o = atomicCAS(&P.owner[s], 0xFFFFFFFFu, me);
-                    if (o == 0xFFFFFFFFu)
-                        o = me;
-                    const uint2 b = P.aux[o >> 1];
-                    if ((P.cand[o >> 1].val >> 11) == pat && b.x == a.x && b.y - (o & 1u) == band) {
-                        atomicAdd(&P.count[s], 1u);
-                        if (o == me)
-                            claimed[sec] = s;
-                        break;
-                    }
-                    s = (s + 1) & P.table_mask;
-                }
-            }
-        }
-        P.own_slot[i] = make_uint2(claimed[0], claimed[1]);
-    }
-}
-
-// one thread per candidate: the claimer of a band emits it if the band collected enough seed hits
-__global__ void merge_select_kernel(const merge_params P)
-{
-    unsigned long long n = P.counters[1];
-    if (n > P.cand_cap)
-        n = P.cand_cap;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint2 mine = P.own_slot[i];
-        if (mine.x == 0xFFFFFFFFu && mine.y == 0xFFFFFFFFu)
-            continue;
-        const uint32_t pat = P.cand[i].val >> 11;
-        const uint2 a = P.aux[i];
-        const int64_t sb = P.seg_offsets ? (int64_t)P.seg_offsets[a.x] : (int64_t)P.hay_begin;
-        for (uint32_t sec = 0; sec < 2; ++sec) {
-            const uint32_t s = sec ? mine.y : mine.x;
-            if (s == 0xFFFFFFFFu || P.count[s] < P.surplus[pat])
-                continue;
-            const uint32_t band = a.y - sec;
-            const int64_t d_lo = sb - (int64_t)P.max_m + (int64_t)band * P.Bw;
-            // last end position the band can produce: diagonal d_lo + Bw + k, needle length m, k more symbols
-            if (P.seg_owned && d_lo + (int64_t)P.Bw + 2 * (int64_t)P.k[pat] + (int64_t)P.m[pat] <= sb + (int64_t)P.seg_owned[a.x])
-                continue; // everything this band can report ends inside the haystack's unwanted prefix
-            const unsigned long long idx = atomicAdd(P.out_count, 1ull);
-            if (idx < P.out_cap) {
-                candidate c;
-                c.t = (uint64_t)(sb - (int64_t)P.max_m + (int64_t)band * P.Bw); // first diagonal of the band
-                c.val = (pat << 11) | (P.Bw + (uint32_t)P.k[pat]);                 // its last diagonal: + Bw + k
-                c.pad = kCandMerged | (a.x + 1);
-                P.out[idx] = c;
-            }
-        }
-    }
+    wave_count_add(P.hit_counter + 7, n_valid); // bands verified
 }
 
 } // namespace spm_hip

@@ -41,15 +41,14 @@ struct filter_index
     uint64_t n_entries = 0;  // entries of the exact table after identical (key, needle) pairs were merged
     uint32_t max_range = 0;  // largest diagonal range of a merged entry
     uint32_t *d_bitmap = nullptr;
-    uint2 *d_ht = nullptr;
-    uint16_t *d_ht_rng = nullptr;
+    uint4 *d_ht = nullptr; // exact table: {key, val, seed signature, range code}
     // host copies, kept only by spm_hip_host_selftest (no device involved)
     std::vector<uint32_t> h_image;
-    std::vector<uint2> h_ht;
-    std::vector<uint16_t> h_rng;
+    std::vector<uint4> h_ht;
 };
 
 static thread_local bool g_index_host_only = false;
+constexpr size_t kMergeRun = 8; // identical (key, needle) entries beyond this many are merged into one with a diagonal range
 
 struct spm_patterns
 {
@@ -81,7 +80,10 @@ struct spm_patterns
     uint32_t *d_offsets = nullptr;  // ... and where each needle starts
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
-    uint32_t filter_max_range = 0; // largest diagonal range over all passes (end-position slots of the verification)
+    uint32_t filter_max_range = 0; // largest diagonal range over all passes
+    pass_entry *d_pass_tab = nullptr; // the passes' exact key tables, for resolve_kernel
+    mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
+    mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
 };
 
 static uint32_t next_pow2(uint32_t x)
@@ -182,7 +184,6 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                 for (filter_index &F : ps->fidx) {
                     hipFree(F.d_bitmap);
                     hipFree(F.d_ht);
-                    hipFree(F.d_ht_rng);
                 }
                 ps->fidx.clear();
                 return SPM_OK; // too many passes to be worth it: brute force
@@ -196,7 +197,6 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                 for (filter_index &G : ps->fidx) {
                     hipFree(G.d_bitmap);
                     hipFree(G.d_ht);
-                    hipFree(G.d_ht_rng);
                 }
                 ps->fidx.clear();
                 return SPM_OK;
@@ -214,7 +214,6 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         for (filter_index &F : ps->fidx) {
             hipFree(F.d_bitmap);
             hipFree(F.d_ht);
-            hipFree(F.d_ht_rng);
         }
         ps->fidx.clear();
     }
@@ -227,9 +226,10 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     F.ok = false;
     struct kv
     {
-        uint32_t key, val;
+        uint32_t key, val, sig, meta;
     };
     std::vector<kv> keys;
+    auto code = [&](uint8_t c) -> uint32_t { return (ps->sigma == 5 && c == 4) ? 3u : (c & 3u); };
     for (uint32_t p = p_begin; p < p_end; ++p) {
         const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
         const seed_plan sp = plan_seeds(m, k);
@@ -241,8 +241,19 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
                 // window seed[r, r+H) -- inside the seed because S <= q - H + 1
                 uint32_t key = 0;
                 for (uint32_t i = 0; i < F.key_len; ++i)
-                    key |= (uint32_t)((ps->sigma == 5 && pat[o + r + i] == 4) ? 3u : (pat[o + r + i] & 3u)) << (2 * i);
-                keys.push_back({key, (p << 11) | (o + r)});
+                    key |= code(pat[o + r + i]) << (2 * i);
+                // signature: the REST of the seed -- its r symbols before the key window, then those after it --, the
+                // first 16 of them, 2 bits each.  With the key that is the whole seed when q <= key_len + 16, so the
+                // resolve kernel checks "the seed occurs here unchanged" in registers (filter.hpp, seed_sig_ok)
+                uint32_t sig = 0, ns = 0;
+                for (uint32_t i = 0; i < r && ns < 16; ++i, ++ns)
+                    sig |= code(pat[o + i]) << (2 * ns);
+                for (uint32_t i = r + F.key_len; i < q && ns < 16; ++i, ++ns)
+                    sig |= code(pat[o + i]) << (2 * ns);
+                // range code of a single entry: where the window sits in its seed (r), how many rest symbols the
+                // signature holds (ns), and whether that is the whole rest (filter.hpp, kRngSingle)
+                const uint32_t meta = kRngSingle | (r & 0xF) | (ns << 4) | (ns == q - F.key_len ? kRngWhole : 0u);
+                keys.push_back({key, (p << 11) | (o + r), sig, meta});
             }
         }
     }
@@ -250,10 +261,14 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     if (F.n_keys == 0)
         return SPM_OK;
     // A periodic seed puts the same key at several offsets of one needle (a homopolymer run: at every shift of every
-    // seed).  Such entries are merged into one with a diagonal range: a text window then yields ONE candidate per needle,
-    // verified over the diagonals of all the offsets, instead of one per offset.  (Not for sets whose candidates are
-    // merged per diagonal band: the band count works on single diagonals.)
+    // seed).  More than kMergeRun such entries -- the needle IS a repeat there -- are merged into one with a diagonal
+    // range: a text window then yields ONE pair per needle, counted into the bands of all the offsets, without per-offset
+    // checks (they would pass wherever the text carries the same repeat).  Shorter runs -- a needle that merely ends in a
+    // repeat -- stay apart, each with its own seed signature.  (Not for sets whose bands count seed hits: the count
+    // works on single diagonals.)
     std::vector<uint16_t> ranges(keys.size(), 0);
+    for (size_t i = 0; i < keys.size(); ++i)
+        ranges[i] = (uint16_t)keys[i].meta;
     const bool band_merging = ps->max_k >= kMergeMinK && ps->max_k <= 1000;
     if (!band_merging && env_int("SPM_HIP_FILTER_DEDUPE", 1) != 0) {
         std::sort(keys.begin(), keys.end(), [](const kv &a, const kv &b) { return a.key != b.key ? a.key < b.key : a.val < b.val; });
@@ -262,10 +277,19 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
             size_t j = i + 1;
             while (j < keys.size() && keys[j].key == keys[i].key && (keys[j].val >> 11) == (keys[i].val >> 11))
                 ++j;
-            keys[w] = keys[i];
-            ranges[w] = (uint16_t)((keys[j - 1].val & 0x7FF) - (keys[i].val & 0x7FF));
-            F.max_range = std::max<uint32_t>(F.max_range, ranges[w]);
-            ++w;
+            if (j - i > kMergeRun) {
+                const uint32_t span = (keys[j - 1].val & 0x7FF) - (keys[i].val & 0x7FF);
+                keys[w] = keys[i];
+                ranges[w] = (uint16_t)(kRngRun | span);
+                F.max_range = std::max<uint32_t>(F.max_range, span);
+                ++w;
+            } else {
+                for (size_t q = i; q < j; ++q) {
+                    keys[w] = keys[q];
+                    ranges[w] = (uint16_t)keys[q].meta;
+                    ++w;
+                }
+            }
             i = j;
         }
         keys.resize(w);
@@ -372,29 +396,25 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     const std::vector<uint32_t> &bitmap = image;
     uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_entries * 2));
     F.ht_mask = ht_size - 1;
-    std::vector<uint2> ht(ht_size, make_uint2(0, kHtEmpty));
-    std::vector<uint16_t> rng(ht_size, 0);
+    // exact table: {key, val = pattern << 11 | offset, seed signature, range code}, val == kHtEmpty marks an empty slot
+    std::vector<uint4> ht(ht_size, make_uint4(0, kHtEmpty, 0, 0));
     for (size_t i = 0; i < keys.size(); ++i) {
         const kv &e = keys[i];
         uint32_t slot = ht_hash(e.key) & F.ht_mask;
         while (ht[slot].y != kHtEmpty)
             slot = (slot + 1) & F.ht_mask;
-        ht[slot] = make_uint2(e.key, e.val);
-        rng[slot] = ranges[i];
+        ht[slot] = make_uint4(e.key, e.val, e.sig, ranges[i]);
     }
     if (g_index_host_only) {
         F.h_image = bitmap;
         F.h_ht = ht;
-        F.h_rng = rng;
         F.ok = true;
         return SPM_OK;
     }
     SPM_HIP_CHECK(ctx, hipMalloc(&F.d_bitmap, words * sizeof(uint32_t)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint2)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht_rng, ht_size * sizeof(uint16_t)));
+    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint4)));
     SPM_HIP_CHECK(ctx, hipMemcpy(F.d_bitmap, bitmap.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht, ht.data(), ht_size * sizeof(uint2), hipMemcpyHostToDevice));
-    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht_rng, rng.data(), ht_size * sizeof(uint16_t), hipMemcpyHostToDevice));
+    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht, ht.data(), ht_size * sizeof(uint4), hipMemcpyHostToDevice));
     F.ok = true;
     return SPM_OK;
 }
@@ -529,8 +549,14 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         if (rc != SPM_OK)
             return rc;
         if (!ps->fidx.empty()) {
-            const size_t nr = std::max<size_t>(ps->ranks.size(), 1);
+            std::vector<pass_entry> pt;
+            for (const filter_index &F : ps->fidx)
+                pt.push_back(pass_entry{F.d_ht, F.ht_mask, 0});
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_pass_tab, pt.size() * sizeof(pass_entry)));
+            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_pass_tab, pt.data(), pt.size() * sizeof(pass_entry), hipMemcpyHostToDevice));
+            const size_t nr = ps->ranks.size() + 64; // padded: resolve_kernel reads whole dwords around a seed
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_ranks, nr));
+            SPM_HIP_CHECK(ctx, hipMemset(ps->d_ranks, 0, nr));
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_offsets, ps->offsets.size() * sizeof(uint32_t)));
             if (!ps->ranks.empty())
                 SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
@@ -562,10 +588,10 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_surplus);
     hipFree(p->d_ranks);
     hipFree(p->d_offsets);
+    hipFree(p->d_pass_tab);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
-        hipFree(F.d_ht_rng);
     }
     delete p;
 }
@@ -766,6 +792,8 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
+    hipFree(ctx->d_band_keys);
+    hipFree(ctx->d_band_val);
     delete ctx;
 }
 
@@ -988,7 +1016,9 @@ struct scan_args
     uint64_t n_segments = 0;
     const uint64_t *d_seg_offsets = nullptr; // the same table already resident on the device (journaled-sequence index)
     const uint32_t *d_seg_owned = nullptr;   // optional per-segment offset of the first wanted end symbol (filter engine)
-    uint64_t cand_cap_override = 0;          // retry after a candidate overflow: the count the first attempt needed
+    uint64_t cand_cap_override = 0;          // retry after a survivor overflow: the count the first attempt needed
+    uint64_t band_scale = 0;                 // retry after a band list / table overflow: that much more room
+    bool seen_full = false;                  // retry after a dedupe-set overflow: size it for the caller's hit buffer
     std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
     // span-local fallback: the filter run leaves these for the brute-force re-scan of the spans that gave up
     unsigned long long *d_seen = nullptr;
@@ -1239,55 +1269,101 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
     return SPM_OK;
 }
 
+// persistent band table of the context: empty between scans (the verification gives every slot back), so a scan pays
+// for the bands it has, not for a memset of the table
+int ensure_band_table(spm_ctx *ctx, uint64_t slots)
+{
+    if (ctx->band_slots >= slots && !ctx->band_dirty)
+        return SPM_OK;
+    if (ctx->band_slots < slots) {
+        if (ctx->d_band_keys) {
+            SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->d_band_keys);
+            hipFree(ctx->d_band_val);
+            ctx->d_band_keys = nullptr;
+            ctx->d_band_val = nullptr;
+            ctx->band_slots = 0;
+        }
+        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_keys, slots * sizeof(unsigned long long)));
+        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_val, slots * sizeof(unsigned long long)));
+        ctx->band_slots = slots;
+    }
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_keys, 0xFF, ctx->band_slots * sizeof(unsigned long long), ctx->stream));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_val, 0, ctx->band_slots * sizeof(unsigned long long), ctx->stream));
+    ctx->band_dirty = false;
+    return SPM_OK;
+}
+
 int run_filter(const scan_args &A)
 {
     spm_ctx *ctx = A.ctx;
     const spm_patterns *ps = A.ps;
     spm_hits *H = A.hits;
-    // scratch: candidates + dedupe set
     const uint64_t kmax = ps->max_k;
-    constexpr uint64_t kCandMax = 1ull << 26; // 1 GiB of candidates: beyond that spans give up (brute-force re-scan)
-    uint64_t cand_cap = std::max<uint64_t>(4096, 8ull * ps->n * (kmax + 1)); // a handful of true seed hits per needle
-    // real texts are not uniform: room for the seed hits of repeat stretches (one candidate per 256 symbols)
-    cand_cap = std::max<uint64_t>(cand_cap, (A.end - A.begin) / 256);
+    // ---- sizes: survivor list, band list, band table, dedupe set ----
+    constexpr uint64_t kSurvMax = 1ull << 27; // 2 GiB of survivors: beyond that spans give up (brute-force re-scan)
+    uint64_t est = std::max<uint64_t>(4096, 8ull * ps->n * (kmax + 1)); // a handful of true seed hits per needle
+    // real texts are not uniform: room for the seed hits of repeat stretches (one survivor per 512 symbols)
+    est = std::max<uint64_t>(est, (A.end - A.begin) / 512);
     // chance hits of short keys: windows looked at x keys / 4^key_len, per pass (negligible for 16-symbol keys)
     double chance = 0;
     for (const filter_index &F : ps->fidx)
         chance += (double)(A.end - A.begin) / std::max(1u, F.stride) * (double)F.n_keys / std::pow(4.0, (double)F.key_len);
-    cand_cap = std::max<uint64_t>(cand_cap, (uint64_t)(2.0 * chance));
-    cand_cap = std::max<uint64_t>(cand_cap, ps->cand_hint + ps->cand_hint / 4);
-    cand_cap += (uint64_t)ctx->n_cu * 16 * kCandChunk; // slots are drawn in chunks per wave: room for the tails
-    cand_cap = std::min(cand_cap, kCandMax);
+    est = std::max<uint64_t>(est, (uint64_t)(2.0 * chance));
+    est = std::max<uint64_t>(est, ps->cand_hint + ps->cand_hint / 4);
+    // slots are drawn in growing chunks per wave (unused tails stay invalid): twice the estimate + the first chunks
+    uint64_t surv_cap = std::min(2 * est + (uint64_t)ctx->n_cu * 16 * kChunkMin, kSurvMax);
     if (A.cand_cap_override)
-        cand_cap = A.cand_cap_override;
+        surv_cap = A.cand_cap_override;
     const int cc = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
     if (cc > 0)
-        cand_cap = (uint64_t)cc;
-    // dedupe set: one key per reported hit, so twice the hit capacity is room enough
-    uint64_t seen_slots = 1u << 16;
-    while (seen_slots < 2 * std::min<uint64_t>(cand_cap * (2 * kmax + 1 + ps->filter_max_range), std::max<uint64_t>(H->cap, 1)))
-        seen_slots <<= 1;
-    const size_t cand_bytes = cand_cap * sizeof(candidate);
-    const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
-    // candidate merging (needles with many errors): bands, per-candidate aux, band table
-    const bool merging = ps->d_surplus != nullptr && env_int("SPM_HIP_FILTER_MERGE", 1) != 0;
+        surv_cap = (uint64_t)cc;
+    // (+ the first chunk of every wave of resolve_kernel: n_cu x 8 workgroups of 4 waves)
+    const uint64_t band_cap = std::max<uint64_t>(surv_cap, 4096) * (A.band_scale ? A.band_scale : 1) +
+                              (uint64_t)ctx->n_cu * 32 * kChunkMin;
     uint64_t band_slots = 1u << 12;
-    while (merging && band_slots < 4 * cand_cap)
+    while (band_slots < 2 * band_cap)
         band_slots <<= 1;
-    const size_t merged_bytes = 2 * cand_bytes; // merged bands, or the compacted candidate list
-    const size_t aux_bytes = merging ? 2 * cand_cap * sizeof(uint2) : 0; // {segment, band} + the table slots claimed
-    const size_t table_bytes = merging ? band_slots * 2 * sizeof(uint32_t) : 0;
+    // bands: Bw diagonals each.  Sets with surplus seeds: (k+1) x factor, overlapping by k + 1 (wider bands mean fewer
+    // occurrences whose seeds straddle two of them at the price of more end positions per verification; 4(k+1) measured
+    // best for |P| = 1024, k = 64; the lane-per-band kernel keeps its end-position slots per thread: narrow bands there).
+    // Other sets: 64 diagonals, no overlap -- every band with a seed hit is verified.
+    uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
+    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-band kernel
+    const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min;
+    const bool overlap = ps->d_surplus != nullptr;
+    uint32_t Bw;
+    if (overlap) {
+        const uint32_t bw_factor = use_wave ? (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_BAND_FACTOR", 4)) : 1u;
+        Bw = (ps->max_k + 1) * bw_factor;
+        if (Bw + ps->max_k > 2047)
+            Bw = ps->max_k + 1;
+    } else {
+        Bw = (uint32_t)std::max(8, std::min(64, env_int("SPM_HIP_FILTER_BAND", 32))); // (one mask bit per diagonal)
+    }
+    const uint32_t max_span = Bw - 1 + (overlap ? ps->max_k + 1 : 0);
+    // dedupe set: one key per reported hit, so twice the hit capacity is room enough; a caller with a huge hit buffer
+    // (repeat-rich texts) pays for what earlier scans of this needle set actually reported
+    uint64_t want_seen = std::min<uint64_t>(band_cap * (2 * kmax + 1 + max_span), std::max<uint64_t>(H->cap, 1));
+    if (!A.seen_full)
+        want_seen = std::min<uint64_t>(want_seen, std::max<uint64_t>(1u << 18, 4 * ps->hit_hint));
+    uint64_t seen_slots = 1u << 16;
+    while (seen_slots < 2 * want_seen)
+        seen_slots <<= 1;
+    const size_t surv_bytes = surv_cap * sizeof(survivor);
+    const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
+    const size_t band_bytes = band_cap * sizeof(band_rec);
     const size_t ovf_bytes = kOvfCap * 2 * sizeof(uint64_t);
-    int rc = ensure_scratch(ctx, cand_bytes + seen_bytes + merged_bytes + aux_bytes + table_bytes + ovf_bytes);
+    int rc = ensure_scratch(ctx, surv_bytes + seen_bytes + band_bytes + ovf_bytes);
     if (rc != SPM_OK)
         return rc;
-    candidate *d_cand = (candidate *)ctx->d_scratch;
-    unsigned long long *d_seen = (unsigned long long *)((uint8_t *)ctx->d_scratch + cand_bytes);
-    candidate *d_merged = (candidate *)((uint8_t *)d_seen + seen_bytes);
-    uint2 *d_aux = (uint2 *)((uint8_t *)d_merged + merged_bytes);
-    uint32_t *d_band_owner = (uint32_t *)((uint8_t *)d_aux + aux_bytes);
-    uint32_t *d_band_count = d_band_owner + band_slots;
-    uint64_t *d_ovf = (uint64_t *)((uint8_t *)d_band_owner + table_bytes);
+    rc = ensure_band_table(ctx, band_slots);
+    if (rc != SPM_OK)
+        return rc;
+    survivor *d_surv = (survivor *)ctx->d_scratch;
+    unsigned long long *d_seen = (unsigned long long *)((uint8_t *)ctx->d_scratch + surv_bytes);
+    band_rec *d_bands = (band_rec *)((uint8_t *)d_seen + seen_bytes);
+    uint64_t *d_ovf = (uint64_t *)((uint8_t *)d_bands + band_bytes);
     {
         scan_args &W = const_cast<scan_args &>(A);
         W.d_seen = d_seen;
@@ -1295,10 +1371,7 @@ int run_filter(const scan_args &A)
         W.d_ovf = d_ovf;
     }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
-    if (merging) {
-        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_band_owner, 0xFF, band_slots * sizeof(uint32_t), ctx->stream));
-        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_band_count, 0, band_slots * sizeof(uint32_t), ctx->stream));
-    }
+    ctx->band_dirty = true; // until the verification has consumed every band of this scan
 
     filter_params P{};
     P.text = A.text->d;
@@ -1307,9 +1380,9 @@ int run_filter(const scan_args &A)
     const uint64_t reach = ps->max_window;
     P.lo = A.begin >= A.ctx_begin + reach ? A.begin - reach : A.ctx_begin;
     P.hi = A.end;
-    P.cand = d_cand;
+    P.surv = d_surv;
     P.counters = H->d_count;
-    P.cand_cap = cand_cap;
+    P.surv_cap = surv_cap;
     P.ovf_spans = d_ovf;
     P.ovf_cap = kOvfCap;
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[1], ctx->stream));
@@ -1325,9 +1398,7 @@ int run_filter(const scan_args &A)
     P.chd_disp_off = F.chd_disp_off;
     P.n_probes = F.n_probes;
     P.bitmap = F.d_bitmap;
-    P.ht = F.d_ht;
-    P.ht_rng = F.d_ht_rng;
-    P.ht_mask = F.ht_mask;
+    P.pass = (uint32_t)fi;
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
     const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
@@ -1335,17 +1406,8 @@ int run_filter(const scan_args &A)
     // measured best: 8 waves per CU on the 1-byte text (HBM-bound), 16 on the 2-bit shadow (LDS/VALU-bound)
     const uint32_t threads = (uint32_t)std::max(
         64, std::min(use_packed ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
-    // + the workgroup's span-dequeue slot (4 words) + one candidate-chunk record (4 words) per wave
-    size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4;
-    // strides 1 and 2: survivors are queued in LDS and resolved 64 at a time, if the queues fit beside the table
-    P.queue_cap = 0;
-    {
-        const size_t with_queues = lds + (size_t)(threads / 64) * kQueueWords * 4;
-        if (F.stride <= 2 && with_queues <= 160 * 1024 && env_int("SPM_HIP_FILTER_QUEUE", 1) != 0) {
-            P.queue_cap = kQueueCap;
-            lds = with_queues;
-        }
-    }
+    // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave
+    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4;
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
@@ -1484,6 +1546,61 @@ int run_filter(const scan_args &A)
     }
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[2], ctx->stream));
 
+    // ---- resolve: survivors -> needles -> whole-seed check -> diagonal bands (one launch for all passes) ----
+    const uint64_t *d_seg = nullptr;
+    uint64_t n_seg = 0;
+    if (A.d_seg_offsets) {
+        d_seg = A.d_seg_offsets;
+        n_seg = A.n_segments;
+    } else if (A.seg_offsets) {
+        uint64_t *d = nullptr;
+        SPM_HIP_CHECK(ctx, hipMalloc(&d, (A.n_segments + 1) * sizeof(uint64_t)));
+        hipFree(H->d_aux[1]);
+        H->d_aux[1] = d;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d, A.seg_offsets, (A.n_segments + 1) * sizeof(uint64_t),
+                                          hipMemcpyHostToDevice, ctx->stream));
+        d_seg = d;
+        n_seg = A.n_segments;
+    }
+    uint32_t seg_bits = 0;
+    while (n_seg && (1ull << seg_bits) < n_seg + 1)
+        ++seg_bits;
+    resolve_params R{};
+    R.surv = d_surv;
+    R.counters = H->d_count;
+    R.surv_cap = surv_cap;
+    R.passes = ps->d_pass_tab;
+    R.key_len = ps->filter_key_len;
+    R.text = A.text->d;
+    R.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
+    R.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
+    R.needle_offsets = ps->d_offsets;
+    R.flank_check = (ps->sigma == 4 && !overlap && R.needle_ranks && env_int("SPM_HIP_FLANK_CHECK", 1)) ? 1u : 0u;
+    R.pieces_check = env_int("SPM_HIP_PIECES_CHECK", 1) ? R.flank_check : 0u;
+    R.m = ps->d_m;
+    R.k = ps->d_k;
+    R.hay_begin = A.ctx_begin;
+    R.hay_end = A.end;
+    R.seg_offsets = d_seg;
+    R.n_segments = n_seg;
+    R.Bw = Bw;
+    R.overlap = overlap ? 1u : 0u;
+    R.max_m = ps->max_m;
+    R.band_bits = 43 - seg_bits;
+    R.band_keys = ctx->d_band_keys;
+    R.band_val = ctx->d_band_val;
+    R.table_mask = (uint32_t)(band_slots - 1);
+    R.bands = d_bands;
+    R.band_cap = band_cap;
+    // grid: what earlier scans of this needle set produced (a full grid of idle workgroups costs ~30 us on a 2.6 ms scan);
+    // a scan that produces more simply loops
+    const uint64_t surv_expect = ps->cand_hint ? 2 * ps->cand_hint : surv_cap;
+    const uint64_t rmax = (uint64_t)ctx->n_cu * (uint64_t)std::max(1, env_int("SPM_HIP_RESOLVE_WGS_PER_CU", 8));
+    const uint32_t rgrid = (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(ctx->n_cu / 2, (surv_expect + 255) / 256));
+    hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, R);
+    SPM_HIP_CHECK(ctx, hipGetLastError());
+
+    // ---- verification: one band = one verification ----
     verify_params V{};
     V.text = A.text->d;
     V.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
@@ -1491,18 +1608,20 @@ int run_filter(const scan_args &A)
     V.scan_begin = A.begin;
     V.scan_end = A.end;
     V.pos_offset = A.opts.pos_offset;
-    V.cand = d_cand;
+    V.bands = d_bands;
     V.counters = H->d_count;
-    V.cand_cap = cand_cap;
+    V.band_cap = band_cap;
+    V.band_keys = ctx->d_band_keys;
+    V.band_val = ctx->d_band_val;
+    V.surplus = ps->d_surplus;
+    V.Bw = Bw;
+    V.overlap = overlap ? 1u : 0u;
+    V.max_m = ps->max_m;
     V.peq32 = ps->d_peq_verify ? ps->d_peq_verify : ps->d_peq;
     V.sigma = ps->sigma;
     V.nw_table = ps->NW;
     V.max_k = ps->max_k;
-    V.max_span = ps->filter_max_range; // raw candidates of merged (periodic) entries answer for a range of diagonals
-    V.key_len = ps->filter_key_len;
-    V.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
-    V.needle_offsets = ps->d_offsets;
-    V.text_sigma = ps->sigma;
+    V.max_span = max_span;
     V.m = ps->d_m;
     V.k = ps->d_k;
     V.report_begin = ps->is_myers() ? 0 : 1;
@@ -1512,87 +1631,23 @@ int run_filter(const scan_args &A)
     V.hit_counter = H->d_count;
     V.hit_cap = H->cap;
     V.overflow = H->d_count + 2;
-    if (A.d_seg_offsets) {
-        V.seg_offsets = A.d_seg_offsets;
-        V.n_segments = A.n_segments;
-        V.seg_owned = A.d_seg_owned;
-    } else if (A.seg_offsets) {
-        uint64_t *d_seg = nullptr;
-        SPM_HIP_CHECK(ctx, hipMalloc(&d_seg, (A.n_segments + 1) * sizeof(uint64_t)));
-        hipFree(H->d_aux[1]);
-        H->d_aux[1] = d_seg;
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_seg, A.seg_offsets, (A.n_segments + 1) * sizeof(uint64_t),
-                                          hipMemcpyHostToDevice, ctx->stream));
-        V.seg_offsets = d_seg;
-        V.n_segments = A.n_segments;
-    }
-    V.cand_counter = 1;
-    if (!merging && V.needle_ranks && chance >= 2048.0) {
-        // few errors, long text: drop the candidates whose whole seed does not match (chance matches of the key; a
-        // short text has too few of them to pay for the extra launch) and verify a dense list
-        hipLaunchKernelGGL(compact_candidates_kernel, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, V, d_merged,
-                           H->d_count + 3, cand_cap);
-        SPM_HIP_CHECK(ctx, hipGetLastError());
-        V.cand = d_merged;
-        V.cand_counter = 3;
-        V.needle_ranks = nullptr; // already applied
-    }
-    uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
-    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-candidate kernel
-    const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min;
-    if (!merging && !use_wave)
-        V.needle_ranks = nullptr; // inside the lane-per-candidate kernel the check cannot shorten a wave: leave it out
-    if (merging) {
-        merge_params M{};
-        M.cand = d_cand;
-        M.counters = H->d_count;
-        M.out_count = H->d_count + 3;
-        M.cand_cap = cand_cap;
-        M.m = ps->d_m;
-        M.k = ps->d_k;
-        M.surplus = ps->d_surplus;
-        M.key_len = ps->filter_key_len;
-        M.max_m = ps->max_m;
-        // band width: wider bands mean fewer occurrences whose seeds straddle two bands (each is then verified twice)
-        // at the price of more end positions per verification; 4(k+1) measured best for |P| = 1024, k = 64
-        // (the lane-per-candidate kernel keeps its end-position slots per thread: narrow bands there)
-        const uint32_t bw_factor = use_wave ? (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_BAND_FACTOR", 4)) : 1u;
-        M.Bw = (ps->max_k + 1) * bw_factor;
-        if (M.Bw + ps->max_k > 2047)
-            M.Bw = ps->max_k + 1;
-        M.table_mask = (uint32_t)(band_slots - 1);
-        M.hay_begin = A.ctx_begin;
-        M.seg_offsets = V.seg_offsets;
-        M.n_segments = V.n_segments;
-        M.aux = d_aux;
-        M.own_slot = d_aux + cand_cap;
-        M.seg_owned = V.seg_owned;
-        M.V = V; // the whole-seed check reads the text and the needles through the verification parameters
-        M.owner = d_band_owner;
-        M.count = d_band_count;
-        M.out = d_merged;
-        M.out_cap = 2 * cand_cap;
-        const dim3 mg(ctx->n_cu * 4), mb(256);
-        hipLaunchKernelGGL(merge_aux_kernel, mg, mb, 0, ctx->stream, M);
-        hipLaunchKernelGGL(merge_count_kernel, mg, mb, 0, ctx->stream, M);
-        hipLaunchKernelGGL(merge_select_kernel, mg, mb, 0, ctx->stream, M);
-        SPM_HIP_CHECK(ctx, hipGetLastError());
-        V.cand = d_merged;
-        V.cand_cap = 2 * cand_cap;
-        V.cand_counter = 3;
-        V.max_span = M.Bw + ps->max_k;
-    }
+    V.seg_offsets = d_seg;
+    V.n_segments = n_seg;
+    V.seg_owned = A.d_seg_owned;
     if (use_wave) {
         // one verification is a ~1400-step serial chain: enough waves that every band gets its own right away
         launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
     } else {
         if (nwn > 8)
             nwn = ps->NW; // power of two beyond 8 words
-        launch_verify(nwn, V, dim3(ctx->n_cu * 4), ctx->stream);
+        const uint64_t band_expect = ps->band_hint ? 2 * ps->band_hint : band_cap;
+        const uint32_t vgrid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->n_cu * 4, std::max<uint64_t>(ctx->n_cu / 2, (band_expect + 255) / 256));
+        launch_verify(nwn, V, dim3(vgrid), ctx->stream);
     }
     SPM_HIP_CHECK(ctx, hipGetLastError());
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
-    H->cand_cap = cand_cap;
+    H->cand_cap = surv_cap;
+    H->band_cap = band_cap;
     return SPM_OK;
 }
 
@@ -1703,40 +1758,55 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
 
     if (use_filter) {
         H->stats.engine_used = SPM_ENGINE_FILTER;
-        int rc = run_filter(A);
-        if (rc != SPM_OK)
-            return rc;
-        // overflow check needs the counters: one small D2H copy; on overflow re-run brute force
-        // [0] hits, [1] candidate slots drawn, [2] hard overflow, [3] bands, [5] real candidates, [6] spans that gave up
+        // [0] hits, [1] survivor slots drawn, [2] hard overflow (band list / band table / dedupe set / overflow list),
+        // [3] band slots drawn, [5] candidates, [6] spans that gave up, [7] bands verified
         unsigned long long *c = ctx->h_counters;
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const bool segmented = seg_offsets || d_seg_offsets;
-        // Spans gave up because the candidate BUFFER was full (not their own budget), and a larger buffer is affordable:
-        // the first attempt counted the demand, the second has room.  (Segmented scans have no span budget: the whole
-        // count is known.)
-        if (c[1] > H->cand_cap && c[2] == 0 && H->cand_cap < (1ull << 26) && c[0] <= H->cap &&
-            !env_int("SPM_HIP_FILTER_CAND_CAP", 0)) {
-            A.cand_cap_override = std::min<uint64_t>(1ull << 26, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, segmented ? 0 : 4 * H->cand_cap));
-            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
-            H->stats.main_launches = 0;
+        int rc = SPM_OK;
+        for (int outer = 0; outer < 2; ++outer) { // (second round: the dedupe set was too small for the re-scan's hits)
+        bool again = false;
+        for (int attempt = 0;; ++attempt) {
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
-            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            // the overflow checks need the counters: one small D2H copy
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (c[2] == 0)
+                ctx->band_dirty = false; // every band was consumed: the table is empty again
+            if (c[0] > H->cap || attempt == 2)
+                break;
+            // Start over with more room when the lists were too small for this text (the first attempt counted the
+            // demand): survivor buffer full -- spans gave up for that reason, not for their own budget --, or band list /
+            // band table / dedupe set full.  Segmented scans have no span budget: their survivor count is exact.
+            const bool more_surv = c[1] > H->cand_cap && H->cand_cap < (1ull << 27) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0);
+            const bool more_bands = c[2] != 0 && c[3] > H->band_cap && H->band_cap < (1ull << 28);
+            const bool more_seen = c[2] != 0 && !A.seen_full && !more_bands && c[3] <= H->band_cap;
+            if (!more_surv && !more_bands && !more_seen)
+                break;
+            if (more_surv)
+                A.cand_cap_override = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, segmented ? 0 : 4 * H->cand_cap));
+            if (more_bands)
+                A.band_scale = std::max<uint64_t>(1, A.band_scale) * std::max<uint64_t>(2, (c[3] + H->band_cap - 1) / H->band_cap + 1);
+            if (more_seen)
+                A.seen_full = true;
+            SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            H->stats.main_launches = 0;
         }
         H->stats.n_candidates = c[5];
-        H->stats.n_bands = (uint32_t)c[3];
-        if (c[6] == 0 && c[1] <= H->cand_cap)
+        H->stats.n_bands = (uint32_t)std::min<unsigned long long>(c[7], 0xFFFFFFFFull);
+        if (c[2] == 0 && c[6] == 0 && c[1] <= H->cand_cap) {
             patterns->cand_hint = std::max<uint64_t>(patterns->cand_hint, c[1]);
+            patterns->hit_hint = std::max<uint64_t>(patterns->hit_hint, c[0]);
+            patterns->band_hint = std::max<uint64_t>(patterns->band_hint, c[3]);
+        }
         if (c[0] > H->cap) {
             // more hits than the caller's buffer takes: that is the caller's overflow (SPM_E_OVERFLOW from the views,
             // the count so far in stats.n_hits), not a reason to scan again
             H->n = c[0];
             H->counted = true;
         } else if (c[2] != 0 || (segmented && c[1] > H->cand_cap)) {
-            // the dedupe set or the overflow list ran out, or a segmented scan overflowed: the whole range again, brute force
+            // lists still too small, or a segmented scan overflowed: the whole range again, brute force
             H->stats.fell_back = 1;
             use_filter = false;
             SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -1798,8 +1868,15 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
                 SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             }
             H->stats.fallback_symbols = total;
-            if (c[2] != 0 && c[0] <= H->cap) {
-                // the dedupe set ran out during the re-scan: start over with the brute-force engine
+            if (c[2] != 0 && c[0] <= H->cap && !A.seen_full) {
+                // the dedupe set ran out during the re-scan (it was sized for what earlier scans reported): once more,
+                // sized for the caller's hit buffer
+                A.seen_full = true;
+                again = true;
+                H->stats.main_launches = 0;
+                SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            } else if (c[2] != 0 && c[0] <= H->cap) {
+                // still not enough: start over with the brute-force engine
                 H->stats.fell_back = 1;
                 use_filter = false;
                 SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -1810,6 +1887,9 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         } else {
             H->n = c[0];
             H->counted = true;
+        }
+        if (!again)
+            break;
         }
     }
     if (!use_filter) {
@@ -2008,9 +2088,10 @@ extern "C" uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat,
 }
 
 extern "C" uint64_t spm_hip_synth_repeat_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p,
-                                                 uint32_t L, uint32_t kmax, uint32_t repeat_ppm, uint8_t *out)
+                                                 uint32_t L, uint32_t kmax, uint32_t repeat_ppm, uint32_t across_every,
+                                                 uint8_t *out)
 {
-    return synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm, out);
+    return synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm, across_every, out);
 }
 
 extern "C" void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, uint64_t begin, uint64_t n, uint8_t *out)
@@ -2072,12 +2153,15 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     auto level2 = [&](const filter_index &F, uint32_t key, uint32_t val) -> bool {
         uint32_t slot = ht_hash(key) & F.ht_mask;
         for (;;) {
-            const uint2 e = F.h_ht[slot];
+            const uint4 e = F.h_ht[slot];
             if (e.y == kHtEmpty)
                 return false;
-            if (e.x == key && (e.y >> 11) == (val >> 11) && (e.y & 0x7FF) <= (val & 0x7FF) &&
-                (val & 0x7FF) <= (e.y & 0x7FF) + F.h_rng[slot])
-                return true; // the entry, or the merged entry whose diagonal range covers this offset
+            if (e.x == key && (e.y >> 11) == (val >> 11)) {
+                // the entry itself, or a run whose diagonal range covers this offset
+                const uint32_t x0 = e.y & 0x7FF, x = val & 0x7FF;
+                if (!(e.w & kRngRun) ? x == x0 : (x >= x0 && x <= x0 + (e.w & 0x7FF)))
+                    return true;
+            }
             slot = (slot + 1) & F.ht_mask;
         }
     };

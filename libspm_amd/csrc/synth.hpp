@@ -195,13 +195,15 @@ inline uint64_t synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_
     return synth_pattern_at([&](uint64_t i) { return synth_base(seed_text, i); }, o, seed_pat, p, L, kmax, out);
 }
 
-// Needles of the repeat-rich workload: as above over repeat_base; every needle with p % 8 == 7 is cut ACROSS a stretch
-// (the first block at or after a pseudo-random one that holds a stretch), overlapping it by 1 .. min(L, len) bases.
+// Needles of the repeat-rich workload: as above over repeat_base -- cut at uniformly random positions, so they cross a
+// stretch at the natural rate (about (136 + L) / 1024 x the block probability: 1.7 % for L = 100 at ppm = 10 000) -- and
+// on top of that every needle with p % every == every - 1 is cut ACROSS a stretch on purpose (the first block at or
+// after a pseudo-random one that holds a stretch), overlapping it by 1 .. min(L, len) bases.
 inline uint64_t synth_repeat_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
-                                     uint32_t kmax, uint32_t ppm, uint8_t *out)
+                                     uint32_t kmax, uint32_t ppm, uint32_t every, uint8_t *out)
 {
     uint64_t o = pat_rnd(seed_pat, p, 0) % (n_total - 2ull * L);
-    if ((p & 7u) == 7u && ppm > 0) {
+    if (every > 0 && p % every == every - 1 && ppm > 0) {
         const uint64_t n_blocks = n_total >> 10;
         uint64_t b = n_blocks ? pat_rnd(seed_pat, p, 200) % n_blocks : 0;
         for (uint32_t tries = 0; tries < 65536 && n_blocks; ++tries, b = (b + 1) % n_blocks) {

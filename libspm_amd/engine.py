@@ -247,9 +247,10 @@ def synth_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, k
     return out, int(o)
 
 
-def synth_repeat_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, kmax: int, repeat_ppm: int):
+def synth_repeat_pattern(seed_text: int, seed_pat: int, n_total: int, p: int, L: int, kmax: int, repeat_ppm: int,
+                         across_every: int = 8):
     out = np.empty(L, dtype=np.uint8)
-    o = capi.lib().spm_hip_synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm,
+    o = capi.lib().spm_hip_synth_repeat_pattern(seed_text, seed_pat, n_total, p, L, kmax, repeat_ppm, across_every,
                                                 out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out, int(o)
 

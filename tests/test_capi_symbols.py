@@ -27,7 +27,7 @@ def test_version_and_struct_layout(spm):
     assert ctypes.sizeof(spm.capi.Hit) == 16
     assert spm.HIT_DTYPE.itemsize == 16
     assert ctypes.sizeof(spm.capi.ScanOpts) == 32
-    assert ctypes.sizeof(spm.capi.ScanStats) == 48
+    assert ctypes.sizeof(spm.capi.ScanStats) == 64
     # journaled-sequence records (static_assert'ed to the same sizes in csrc/jst.hpp)
     assert ctypes.sizeof(spm.capi.JstAllele) == 24 and spm.ALLELE_DTYPE.itemsize == 24
     assert ctypes.sizeof(spm.capi.JstHit) == 24 and spm.JST_HIT_DTYPE.itemsize == 24

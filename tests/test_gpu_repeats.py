@@ -47,7 +47,7 @@ def test_repeat_rich_text_filter_equals_brute_and_oracle(spm, ctx, oracle, ppm):
     assert len(np.unique(hf.view()["pattern"])) == len(needles)
 
 
-@pytest.mark.parametrize("budget", [1, 4, 64])
+@pytest.mark.parametrize("budget", [1, 3, 8])
 def test_partial_fallback_is_exact(spm, ctx, oracle, budget):
     """A tiny per-span budget forces spans to give up; only those are brute-scanned, hits stay bit-exact and unique."""
     n = 1 << 22
@@ -61,7 +61,7 @@ def test_partial_fallback_is_exact(spm, ctx, oracle, budget):
         del os.environ["SPM_HIP_FILTER_SPAN_BUDGET"]
     assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
     assert st.fallback_spans > 0 and 0 < st.fallback_symbols
-    if budget >= 64:
+    if budget >= 3:
         assert st.fallback_symbols < n  # partial: the quiet spans kept the filter's result
     want = _oracle(oracle, T, needles, 3)
     assert _hits_list(got) == want
