@@ -525,8 +525,10 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
 // of the text goes through a guarded one-chunk loop (bytes past the end read as 0).
 // 512 threads: 8 waves per CU is the measured best for the HBM-bound 1-byte text, and a bound of 1024 leaves 128 VGPRs,
 // which made the masked-key stride-2 variant spill to scratch inside the streaming loop (+31 % kernel time).
+// Stride 1 without key masks (C4-sized needle sets: LDS-bound at 16 windows per lane, see DESIGN) fits 128 VGPRs and may run
+// 16 waves per CU.
 template <int S, int U, bool NT, int HV, int SIG, bool KM>
-__global__ __launch_bounds__(512) void seed_filter_kernel(const filter_params P)
+__global__ __launch_bounds__((S == 1 && !KM && SIG == 4) ? 1024 : 512) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
     // ---- stage the level-1 table in LDS (once per workgroup; the grid is persistent) ----
@@ -781,7 +783,9 @@ struct verify_params
     uint64_t scan_end;
     uint64_t pos_offset;
     const band_rec *bands;
-    const unsigned long long *counters; // [3] band slots drawn
+    const unsigned long long *counters; // [band_counter] = entries of the band list
+    uint32_t band_counter;              // 3: the list resolve_kernel wrote; 10: the list band_select_kernel kept
+    uint32_t preselected;               // 1: the list holds only bands with enough seed hits, their table slots reset
     uint64_t band_cap;
     unsigned long long *band_keys;      // band table (reset slot by slot as the bands are consumed)
     unsigned long long *band_val;       // overlapping bands: seed hits counted; else: bit mask of the diagonals hit
@@ -1306,6 +1310,45 @@ __device__ __forceinline__ bool seen_insert(const verify_params &P, uint32_t pat
     return false;
 }
 
+// Sets with surplus seeds (k >= kMergeMinK): most bands hold a single chance match of a short key and are NOT verified.
+// This pass keeps the bands that collected enough seed hits -- a dense list, so the wave-per-band verification (one
+// ~0.2 ms serial chain per band) gets one band per wave instead of two on some and none on most -- and gives every table
+// slot back.
+__global__ __launch_bounds__(256) void band_select_kernel(const verify_params P, band_rec *out, unsigned long long *out_count)
+{
+    unsigned long long n = P.counters[3];
+    if (n > P.band_cap)
+        n = P.band_cap;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool keep = false;
+        band_rec c;
+        c.val = kBandInvalid;
+        if (i < n) {
+            c = P.bands[i];
+            if (c.val != kBandInvalid) {
+                const uint32_t cnt = (uint32_t)P.band_val[c.slot];
+                P.band_val[c.slot] = 0;
+                P.band_keys[c.slot] = kBandEmpty;
+                keep = cnt >= (P.surplus ? (uint32_t)P.surplus[c.val >> 11] : 1u);
+            }
+        }
+        const uint64_t m = __ballot(keep);
+        if (m != 0) {
+            unsigned long long base = 0;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            if ((int)lane == leader)
+                base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader);
+            if (keep)
+                out[base + __popcll(m & ((1ull << lane) - 1))] = c; // (<= the entries of the input list)
+        }
+    }
+}
+
 // What a band record stands for (verification side).  Returns false if the band has too few seed hits, lies outside the
 // owned range, or is an unused list slot.  Consumes the band's table slot (the table is empty again after the scan).
 struct band_geom
@@ -1321,13 +1364,16 @@ __device__ __forceinline__ bool decode_band(const verify_params &P, const band_r
     if (c.val == kBandInvalid)
         return false;
     g.pat = c.val >> 11;
-    const unsigned long long v = P.band_val[c.slot];
-    if (consume) {
-        P.band_val[c.slot] = 0;
-        P.band_keys[c.slot] = kBandEmpty;
+    unsigned long long v = 1;
+    if (!P.preselected) {
+        v = P.band_val[c.slot];
+        if (consume) {
+            P.band_val[c.slot] = 0;
+            P.band_keys[c.slot] = kBandEmpty;
+        }
+        if (P.overlap ? (uint32_t)v < (P.surplus ? (uint32_t)P.surplus[g.pat] : 1u) : v == 0)
+            return false;
     }
-    if (P.overlap ? (uint32_t)v < (P.surplus ? (uint32_t)P.surplus[g.pat] : 1u) : v == 0)
-        return false;
     g.m = P.m[g.pat];
     g.k = P.k[g.pat];
     int64_t own_b = (int64_t)P.scan_begin, own_e = (int64_t)P.scan_end, hay_b = (int64_t)P.ctx_begin;
@@ -1378,7 +1424,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
     const uint32_t n_slots = 2 * P.max_k + 1 + P.max_span;
     for (uint32_t r = 0; r < n_slots; ++r)
         hitbuf[(size_t)r * nthr + tid] = 0;
-    unsigned long long n_cand = P.counters[3];
+    unsigned long long n_cand = P.counters[P.band_counter];
     if (n_cand > P.band_cap)
         n_cand = P.band_cap; // overflow is handled by the host
     const uint64_t stride = (uint64_t)gridDim.x * nthr;
@@ -1506,7 +1552,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
     uint8_t *tw = gbase + ((n_slots * 2 + 15) & ~15u);
     for (uint32_t r = gl; r < n_slots; r += G)
         hb[r] = 0;
-    unsigned long long n_cand = P.counters[3];
+    unsigned long long n_cand = P.counters[P.band_counter];
     if (n_cand > P.band_cap)
         n_cand = P.band_cap;
     const uint64_t stride = (uint64_t)gridDim.x * waves * GPW;
@@ -1539,7 +1585,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             ws = g.ws;
         }
         __builtin_amdgcn_wave_barrier();
-        if (gl == 0 && c.val != kBandInvalid) { // ... then one of them gives the table slot back
+        if (gl == 0 && c.val != kBandInvalid && !P.preselected) { // ... then one of them gives the table slot back
             P.band_val[c.slot] = 0;
             P.band_keys[c.slot] = kBandEmpty;
         }

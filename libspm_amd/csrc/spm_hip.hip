@@ -1352,7 +1352,7 @@ int run_filter(const scan_args &A)
         seen_slots <<= 1;
     const size_t surv_bytes = surv_cap * sizeof(survivor);
     const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
-    const size_t band_bytes = band_cap * sizeof(band_rec);
+    const size_t band_bytes = band_cap * sizeof(band_rec) * (overlap ? 2 : 1); // (+ the selected bands of overlapping sets)
     const size_t ovf_bytes = kOvfCap * 2 * sizeof(uint64_t);
     int rc = ensure_scratch(ctx, surv_bytes + seen_bytes + band_bytes + ovf_bytes);
     if (rc != SPM_OK)
@@ -1403,9 +1403,12 @@ int run_filter(const scan_args &A)
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
     const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
                             !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
-    // measured best: 8 waves per CU on the 1-byte text (HBM-bound), 16 on the 2-bit shadow (LDS/VALU-bound)
+    // measured best: 8 waves per CU on the 1-byte text when HBM binds, 16 on the 2-bit shadow and at stride 1 with
+    // 16-symbol keys (LDS-bound: C4 25.8 vs 29.1 ms; the other stride-1/2 variants need more than 128 VGPRs)
+    const bool wide_ok = use_packed || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
+                                        !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
     const uint32_t threads = (uint32_t)std::max(
-        64, std::min(use_packed ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", use_packed ? 1024 : 512)));
+        64, std::min(wide_ok ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", wide_ok ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave
     const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4;
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
@@ -1634,6 +1637,15 @@ int run_filter(const scan_args &A)
     V.seg_offsets = d_seg;
     V.n_segments = n_seg;
     V.seg_owned = A.d_seg_owned;
+    V.band_counter = 3;
+    if (overlap) {
+        hipLaunchKernelGGL(band_select_kernel, dim3(ctx->n_cu * 2), dim3(256), 0, ctx->stream, V, d_bands + band_cap,
+                           H->d_count + 10);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        V.bands = d_bands + band_cap;
+        V.band_counter = 10;
+        V.preselected = 1;
+    }
     if (use_wave) {
         // one verification is a ~1400-step serial chain: enough waves that every band gets its own right away
         launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
