@@ -1749,11 +1749,31 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
 
     const bool has_state = state_in != nullptr;
     const bool want_filter = opts.engine == SPM_ENGINE_FILTER || (opts.engine == SPM_ENGINE_AUTO && !patterns->fidx.empty());
-    if (opts.engine == SPM_ENGINE_FILTER && (patterns->fidx.empty() || has_state)) {
-        SPM_SET_ERR(ctx, "spm_hip_scan: the seed filter does not apply to this needle set / a restored state");
+    if (opts.engine == SPM_ENGINE_FILTER && patterns->fidx.empty()) {
+        SPM_SET_ERR(ctx, "spm_hip_scan: the seed filter does not apply to this needle set");
         return SPM_E_UNSUPPORTED;
     }
-    bool use_filter = want_filter && !has_state && patterns->n > 0 && end > begin;
+    // Restorable scans (myers_matcher_restorable.hpp:72-82: the chunk continues from the restored state).  Only the
+    // first window_size - 1 symbols of a chunk can complete an occurrence that began before it: those are scanned by the
+    // brute-force kernel from the state; from there on every occurrence lies inside the chunk, so the seed filter takes
+    // the rest with the chunk as its haystack.  The state after the last symbol comes from the last 2 max|P| symbols.
+    // Short chunks stay with the brute-force kernel (unless the caller asks for the filter).
+    const bool stateful = has_state || state_out != nullptr;
+    const uint64_t state_prefix = has_state && patterns->max_window > 0 ? patterns->max_window - 1 : 0;
+    bool use_filter = want_filter && patterns->n > 0 && end > begin;
+    if (stateful && use_filter &&
+        (seg_offsets || d_seg_offsets || end - begin <= state_prefix ||
+         (opts.engine != SPM_ENGINE_FILTER && end - begin < (1u << 18))))
+        use_filter = false;
+    if (opts.engine == SPM_ENGINE_FILTER && !use_filter && patterns->n > 0 && end > begin) {
+        SPM_SET_ERR(ctx, "spm_hip_scan: the seed filter does not apply to this stateful scan (chunk shorter than a window)");
+        return SPM_E_UNSUPPORTED;
+    }
+    if (use_filter && has_state) {
+        // the filter's part of a chunk: hits whose last symbol lies at or behind begin + window - 1, haystack = the chunk
+        A.begin = begin + state_prefix;
+        A.ctx_begin = begin;
+    }
 
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[0], ctx->stream));
     H->timed = true;
@@ -1834,7 +1854,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             rg.reserve(n_ovf);
             for (uint64_t i = 0; i < n_ovf; ++i) {
                 const uint64_t b = ov[2 * i], len = ov[2 * i + 1];
-                const uint64_t lo = std::max<uint64_t>(begin, b >= 16 ? b - 16 : 0);
+                const uint64_t lo = std::max<uint64_t>(A.begin, b >= 16 ? b - 16 : 0);
                 const uint64_t hi = std::min<uint64_t>(end, b + len + patterns->max_window);
                 if (lo < hi)
                     rg.emplace_back(lo, hi);
@@ -1903,6 +1923,43 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         if (!again)
             break;
         }
+    }
+    if (use_filter && stateful) {
+        // ---- the brute-force kernel's share of a filtered chunk: its first window - 1 symbols, and the exit state ----
+        A.begin = begin;
+        uint32_t *d_in = nullptr, *d_out = nullptr;
+        std::vector<uint32_t> h_in;
+        const uint32_t rows = patterns->is_myers() ? 2 * patterns->NW + 1 : patterns->NW;
+        const size_t st_words = (size_t)patterns->n_groups * rows * 64;
+        dev_scratch tmp;
+        SPM_HIP_CHECK(ctx, tmp.alloc(&d_in, st_words * 4 * 2));
+        d_out = d_in + st_words;
+        if (has_state) {
+            state_to_internal(patterns, state_in, h_in);
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in.data(), st_words * 4, hipMemcpyHostToDevice, ctx->stream));
+            int rc = run_brute(A, begin, begin + state_prefix, begin, d_in, nullptr, true, true);
+            if (rc != SPM_OK)
+                return rc;
+            H->stats.main_launches--; // (ms_main stays the filter's)
+            H->counted = false;       // more hits may have arrived
+        }
+        if (state_out) {
+            const uint64_t range = end - begin;
+            const uint64_t tail = std::min<uint64_t>(range, 2ull * patterns->max_m + 4);
+            const uint64_t tb = end - tail;
+            const bool from_state = has_state && tb == begin;
+            int rc = run_brute(A, tb, end, tb, from_state ? d_in : nullptr, d_out, false, true);
+            if (rc != SPM_OK)
+                return rc;
+            H->stats.main_launches--;
+        }
+        SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
+        std::vector<uint32_t> h_out(st_words);
+        if (state_out)
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(h_out.data(), d_out, st_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // (h_in is a host temporary; d_in is freed on return)
+        if (state_out)
+            state_from_internal(patterns, h_out, state_out);
     }
     if (!use_filter) {
         H->stats.engine_used = SPM_ENGINE_BRUTE;

@@ -738,3 +738,45 @@ def test_c1_horspool_plumbing(spm, ctx, oracle):
     text = ctx.generate(0x5EED0001, 0, n)
     got = spm.scan(ctx, text, ctx.patterns(spm.ALGO_HORSPOOL, [P])).view()
     assert got["pos"].tolist() == want and set(got["score"].tolist()) == {0}
+
+
+@pytest.mark.parametrize("algo,L,k", [("myers", 100, 3), ("shiftor", 40, 0), ("myers", 64, 1)])
+def test_restorable_chunks_through_the_seed_filter(spm, ctx, oracle, algo, L, k):
+    """Restorable matchers on the HBM-bound engine: chunks >= 1 MiB continue from the restored state
+    -- the brute-force kernel takes the first window - 1 symbols of a chunk, the seed filter the rest -- and hand back a
+    state.  Hits == one sequential scan == oracle; every state blob == the brute-force path's."""
+    n = (3 << 20) + 12345
+    T = oracle.text(0x5EED0001, 0, n)
+    rng = np.random.default_rng(77)
+    needles = [spm.synth_pattern(0x5EED0001, 0x5EED0002, n, p, L, k)[0] for p in range(40)]
+    cuts = [0, 1 << 20, (1 << 20) + 300000, (2 << 20) + 7, n]
+    for c in cuts[1:-1]:                     # occurrences straddling every chunk border, at several phases
+        for j, d in enumerate((-L + 1, -L // 2, -3, 0)):
+            nd = needles[4 * cuts.index(c) + j].copy()
+            if k and j % 2:
+                nd[L // 3] ^= 1
+            T[c + d:c + d + L] = needles[4 * cuts.index(c) + j]
+            needles[4 * cuts.index(c) + j] = nd
+    s_algo = spm.ALGO_MYERS if algo == "myers" else spm.ALGO_SHIFTOR
+    ps = ctx.patterns(s_algo, needles, k=k)
+    assert ps.filterable
+    whole = spm.scan(ctx, ctx.upload(T), ps, engine=spm.ENGINE_BRUTE).view()
+    want = _oracle_multi(oracle, algo, T, needles, [k] * len(needles))
+    assert _hits_list(whole) == want
+    sf, sb = ps.initial_state(), ps.initial_state()
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        chunk = ctx.upload(T[a:b])
+        hf, sf = spm.scan(ctx, chunk, ps, state_in=sf, want_state=True, pos_offset=a, engine=spm.ENGINE_AUTO)
+        hb, sb = spm.scan(ctx, chunk, ps, state_in=sb, want_state=True, pos_offset=a, engine=spm.ENGINE_BRUTE)
+        assert hf.stats().engine_used == spm.ENGINE_FILTER and hb.stats().engine_used == spm.ENGINE_BRUTE
+        assert np.array_equal(sf, sb), "state after the chunk differs between the engines"
+        assert np.array_equal(hf.view(), hb.view())
+        parts.append(hf.view())
+    merged = np.sort(np.concatenate(parts), order=["pattern", "pos"])
+    assert np.array_equal(merged, whole)
+    # want_state without a state to continue from: a fresh matcher's first chunk
+    h0, s0 = spm.scan(ctx, ctx.upload(T[:cuts[1]]), ps, want_state=True, engine=spm.ENGINE_FILTER)
+    hb0, sb0 = spm.scan(ctx, ctx.upload(T[:cuts[1]]), ps, want_state=True, engine=spm.ENGINE_BRUTE)
+    assert h0.stats().engine_used == spm.ENGINE_FILTER
+    assert np.array_equal(s0, sb0) and np.array_equal(h0.view(), hb0.view())
