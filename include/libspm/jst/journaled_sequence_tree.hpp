@@ -348,8 +348,14 @@ public:
         spm_scan_opts opts{};
         opts.max_hits = std::max<std::uint64_t>(1u << 22, 8 * st.context_symbols / window);
         spm_jst_hits * hh = nullptr;
-        if (spm_hip_jst_search(D.tree, needles, &opts, &hh) != SPM_OK)
-            hip::fatal("spm_hip_jst_search", ctx);
+        for (int attempt = 0;; ++attempt) { // (a hit buffer that proves too small is doubled, not fatal)
+            int const rc = spm_hip_jst_search(D.tree, needles, &opts, &hh);
+            if (rc == SPM_OK)
+                break;
+            if (rc != SPM_E_OVERFLOW || attempt >= 12)
+                hip::fatal("spm_hip_jst_search", ctx);
+            opts.max_hits *= 2;
+        }
         spm_jst_hit const * rec = nullptr;
         std::uint64_t n = 0;
         if (spm_hip_jst_hits_view(hh, &rec, &n) != SPM_OK)
@@ -396,14 +402,14 @@ public:
         hip::text_ptr text{t};
         spm_scan_opts opts{};
         opts.max_hits = std::max<std::uint64_t>(1u << 20, 4 * buffer.size() / std::max<std::size_t>(window, 1));
-        spm_hits * hh = nullptr;
-        if (spm_hip_scan_segments(ctx, text.get(), seg.data(), contexts.size(), needles, &opts, &hh) != SPM_OK)
-            hip::fatal("spm_hip_scan_segments", ctx);
-        hip::hits_ptr hits{hh};
         spm_hit const * rec = nullptr;
         std::uint64_t n = 0;
-        if (spm_hip_hits_view(hits.get(), &rec, &n) != SPM_OK)
-            hip::fatal("spm_hip_hits_view", ctx);
+        hip::hits_ptr hits = hip::scan_all_hits(
+            ctx, opts,
+            [&](spm_scan_opts const & o, spm_hits ** h) {
+                return spm_hip_scan_segments(ctx, text.get(), seg.data(), contexts.size(), needles, &o, h);
+            },
+            rec, n, "spm_hip_scan_segments");
         for (std::uint64_t i = 0; i < n; ++i) {
             // context of this hit
             std::size_t const c =

@@ -65,15 +65,14 @@ public:
         if (spm_hip_text_upload(ctx, ranks, n, _sigma, &t) != SPM_OK)
             hip::fatal("spm_hip_text_upload", ctx);
         hip::text_ptr text{t};
-        spm_scan_opts opts{};
-        spm_hits * h = nullptr;
-        if (spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &opts, nullptr, nullptr, &h) != SPM_OK)
-            hip::fatal("spm_hip_scan", ctx);
-        hip::hits_ptr hits{h};
         spm_hit const * rec = nullptr;
         std::uint64_t cnt = 0;
-        if (spm_hip_hits_view(hits.get(), &rec, &cnt) != SPM_OK)
-            hip::fatal("spm_hip_hits_view", ctx);
+        hip::hits_ptr hits = hip::scan_all_hits(
+            ctx, spm_scan_opts{},
+            [&](spm_scan_opts const & o, spm_hits ** h) {
+                return spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &o, nullptr, nullptr, h);
+            },
+            rec, cnt, "spm_hip_scan");
         for (std::uint64_t i = 0; i < cnt; ++i) {
             std::size_t const m = _lengths[rec[i].pattern];
             finder f = reports_begin_v ? finder{static_cast<std::size_t>(rec[i].pos), static_cast<std::size_t>(rec[i].pos) + m, n, 0}

@@ -92,23 +92,30 @@ protected:
         _patterns = hip::patterns_ptr{p, hip::patterns_deleter{}};
     }
 
-    // one bulk scan of `n` ranks; returns the hits in callback order
-    hip::hits_ptr scan(std::uint8_t const * ranks, std::size_t n, void const * state_in, void * state_out,
-                       hip::text_ptr * keep_text = nullptr) const noexcept
+    // the haystack, resident in HBM for the duration of one operator() call
+    hip::text_ptr upload(std::uint8_t const * ranks, std::size_t n) const noexcept
     {
         spm_ctx * ctx = hip::default_context();
         spm_text * t = nullptr;
         if (spm_hip_text_upload(ctx, ranks, n, _sigma, &t) != SPM_OK)
             hip::fatal("spm_hip_text_upload", ctx);
-        hip::text_ptr text{t};
+        return hip::text_ptr{t};
+    }
+
+    // one bulk scan of text[begin, end); the hits (positions relative to text[0]) in callback order.  A hit buffer that
+    // proves too small is enlarged and the scan repeated (hip::scan_all_hits): the reference's find loop has no limit
+    hip::hits_ptr scan_text(spm_text * text, std::size_t begin, std::size_t end, void const * state_in, void * state_out,
+                            spm_hit const *& rec, std::uint64_t & cnt) const noexcept
+    {
+        spm_ctx * ctx = hip::default_context();
         spm_scan_opts opts{};
         opts.engine = SPM_ENGINE_AUTO;
-        spm_hits * h = nullptr;
-        if (spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &opts, state_in, state_out, &h) != SPM_OK)
-            hip::fatal("spm_hip_scan", ctx);
-        if (keep_text)
-            *keep_text = std::move(text);
-        return hip::hits_ptr{h};
+        return hip::scan_all_hits(
+            ctx, opts,
+            [&](spm_scan_opts const & o, spm_hits ** h) {
+                return spm_hip_scan(ctx, text, begin, end, _patterns.get(), &o, state_in, state_out, h);
+            },
+            rec, cnt, "spm_hip_scan");
     }
 
 public:
@@ -135,29 +142,21 @@ protected:
     template <typename callback_t>
     void run(std::uint8_t const * ranks, std::size_t n, callback_t && callback) noexcept
     {
-        hip::hits_ptr hits = scan(ranks, n, nullptr, nullptr);
-        replay(hits.get(), n, callback);
-    }
-
-    template <typename callback_t>
-    void replay(spm_hits * hits, std::size_t n, callback_t && callback) const noexcept
-    {
+        hip::text_ptr text = upload(ranks, n);
         spm_hit const * rec = nullptr;
         std::uint64_t cnt = 0;
-        if (spm_hip_hits_view(hits, &rec, &cnt) != SPM_OK)
-            hip::fatal("spm_hip_hits_view", hip::default_context());
-        std::size_t const m = _needle.size();
-        for (std::uint64_t i = 0; i < cnt; ++i) {
-            finder f = derived_t::reports_begin
-                           ? finder{static_cast<std::size_t>(rec[i].pos), static_cast<std::size_t>(rec[i].pos) + m, n, 0}
-                           : finder{rec[i].pos >= m ? static_cast<std::size_t>(rec[i].pos) - m : 0,
-                                    static_cast<std::size_t>(rec[i].pos), n, rec[i].score};
-            static_cast<derived_t const *>(this)->on_hit(f);
-            callback(f);
-        }
+        hip::hits_ptr hits = scan_text(text.get(), 0, n, nullptr, nullptr, rec, cnt);
+        for (std::uint64_t i = 0; i < cnt; ++i)
+            callback(make_finder(rec[i], n));
     }
 
-    void on_hit(finder const &) const noexcept {}
+    finder make_finder(spm_hit const & h, std::size_t n) const noexcept
+    {
+        std::size_t const m = _needle.size();
+        return derived_t::reports_begin
+                   ? finder{static_cast<std::size_t>(h.pos), static_cast<std::size_t>(h.pos) + m, n, 0}
+                   : finder{h.pos >= m ? static_cast<std::size_t>(h.pos) - m : 0, static_cast<std::size_t>(h.pos), n, h.score};
+    }
 
 private:
     constexpr friend std::size_t tag_invoke(std::tag_t<spm::window_size>, hip_pattern_base const & me) noexcept

@@ -4,9 +4,12 @@
 // Reference semantics (/root/reference/libspm/libspm/matcher/myers_matcher_restorable.hpp:35-82,
 // shiftor_matcher_restorable.hpp:35-67): the pattern state is initialised ONCE, in the constructor; every
 // operator() call continues from the current state; capture() returns it, restore(state) overwrites it; states are
-// std::semiregular (matcher/concept.hpp:132-148).  capture() called from inside the per-hit callback returns the
-// state AT THAT HIT, because the reference's scan is paused there: here the bulk scan has already finished, so the
-// state at the hit is recomputed on the device by scanning the chunk prefix [0, end of hit) from the entry state.
+// std::semiregular (matcher/concept.hpp:132-148).  The reference's scan is PAUSED while a callback runs, so
+//   * capture() inside a callback returns the state AT THAT HIT: here the bulk scan has already finished, so that state
+//     is computed on the device from the last state captured in this call (or the entry state) over the symbols in
+//     between -- the chunk stays resident in HBM, successive captures cost O(chunk) in total, not O(hits x chunk);
+//   * restore(state) inside a callback makes the rest of the chunk continue from `state`: the hits still pending from
+//     the bulk scan are dropped and the remainder [end of this hit, end of chunk) is scanned again from it.
 #pragma once
 
 #include <libspm/matcher/hip_pattern_base.hpp>
@@ -43,11 +46,12 @@ class restorable_base : public hip_pattern_base<derived_t>
     restorable_base() = default;
 
     matcher_state _state{};
-    // replay context, valid only while callbacks of one operator() call run
-    mutable matcher_state _state_at_hit{};
-    mutable std::uint8_t const * _replay_ranks{nullptr};
-    mutable matcher_state const * _entry_state{nullptr};
-    mutable std::size_t _replay_end{0};
+    // replay context, valid only while the callbacks of one operator() call run
+    mutable spm_text * _replay_text{nullptr};
+    mutable matcher_state _cap_state{}; // state after text[0, _cap_pos) ...
+    mutable std::size_t _cap_pos{0};
+    mutable std::size_t _replay_end{0}; // end of the hit whose callback is running
+    bool _restore_pending{false};
 
     void init_state()
     {
@@ -63,18 +67,37 @@ class restorable_base : public hip_pattern_base<derived_t>
         n = static_cast<derived_t *>(this)->bound(n);
         if (this->_needle.empty())
             return; // empty needle: nothing to find (myers_prefix_matcher_restorable.hpp:39,52)
-        matcher_state const entry = _state;
-        matcher_state out{std::vector<std::uint8_t>(entry.blob().size())};
-        hip::hits_ptr hits = this->scan(ranks, n, entry.blob().data(), out.blob().data());
-        _state = out; // state after the last symbol; what capture() returns once the call has finished
-        _replay_ranks = ranks;
-        _entry_state = &entry;
-        this->replay(hits.get(), n, callback);
-        _replay_ranks = nullptr;
-        _entry_state = nullptr;
+        hip::text_ptr text = this->upload(ranks, n);
+        std::size_t from = 0;
+        for (;;) {
+            matcher_state const entry = _state;
+            matcher_state out{std::vector<std::uint8_t>(entry.blob().size())};
+            spm_hit const * rec = nullptr;
+            std::uint64_t cnt = 0;
+            hip::hits_ptr hits =
+                this->scan_text(text.get(), from, n, entry.blob().data(), out.blob().data(), rec, cnt);
+            _state = out; // state after the last symbol; what capture() returns once the call has finished
+            _replay_text = text.get();
+            _cap_state = entry;
+            _cap_pos = from;
+            bool restarted = false;
+            for (std::uint64_t i = 0; i < cnt && !restarted; ++i) {
+                finder const f = this->make_finder(rec[i], n);
+                _replay_end = f.end_position();
+                _restore_pending = false;
+                callback(f);
+                if (_restore_pending) { // the callback restored a state: the rest of the chunk continues from it
+                    from = std::min(_replay_end, n);
+                    restarted = true;
+                }
+            }
+            _replay_text = nullptr;
+            _restore_pending = false;
+            if (!restarted)
+                break;
+        }
     }
 
-    void on_hit(finder const & f) const noexcept { _replay_end = f.end_position(); }
     std::size_t bound(std::size_t n) const noexcept { return n; }
 
 public:
@@ -82,16 +105,26 @@ public:
 
     state_type const & capture() const noexcept
     {
-        if (_replay_ranks == nullptr)
+        if (_replay_text == nullptr)
             return _state;
-        // inside a callback: the state right after the hit's last symbol
-        matcher_state at{std::vector<std::uint8_t>(_entry_state->blob().size())};
-        std::size_t const upto = derived_t::reports_begin ? _replay_end : _replay_end;
-        hip::hits_ptr ignored = this->scan(_replay_ranks, upto, _entry_state->blob().data(), at.blob().data());
-        _state_at_hit = std::move(at);
-        return _state_at_hit;
+        // inside a callback: the state right after the hit's last symbol, continued from the previous capture
+        if (_replay_end > _cap_pos) {
+            matcher_state at{std::vector<std::uint8_t>(_cap_state.blob().size())};
+            spm_hit const * rec = nullptr;
+            std::uint64_t cnt = 0;
+            hip::hits_ptr ignored =
+                this->scan_text(_replay_text, _cap_pos, _replay_end, _cap_state.blob().data(), at.blob().data(), rec, cnt);
+            _cap_state = std::move(at);
+            _cap_pos = _replay_end;
+        }
+        return _cap_state;
     }
 
-    void restore(state_type state) noexcept { _state = std::move(state); }
+    void restore(state_type state) noexcept
+    {
+        _state = std::move(state);
+        if (_replay_text != nullptr)
+            _restore_pending = true;
+    }
 };
 } // namespace spm

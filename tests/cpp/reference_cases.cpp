@@ -10,6 +10,7 @@
 // callback, copies).  No gtest in this image: a 20-line EXPECT harness, exit code = number of failures.
 #include <algorithm>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include <libspm/matcher/concept.hpp>
@@ -351,6 +352,82 @@ static void container_adapter_cases()
     EXPECT_TRUE(std::ranges::equal(ends, std::vector<std::size_t>{10, 21, 32}));
 }
 
+// What the paused scan of the reference implies for calls made INSIDE the per-hit callback, and the absence of a hit limit
+// in its find loop (seqan_pattern_base.hpp:49-51).
+static void paused_scan_cases()
+{
+    unsigned const errors = 1;
+    auto get_matcher = [&] { return spm::restorable_myers_matcher{needle, errors}; };
+    { // capture() at EVERY hit: each state, resumed on the rest of the haystack, yields exactly the remaining hits
+        auto matcher = get_matcher();
+        using state_t = spm::matcher_state_t<decltype(matcher)>;
+        std::vector<std::pair<std::size_t, state_t>> at;
+        std::vector<std::size_t> all;
+        matcher(haystack, [&](auto const & finder) {
+            all.push_back(seqan2::endPosition(finder));
+            at.emplace_back(seqan2::endPosition(finder), spm::capture(matcher));
+        });
+        EXPECT_EQ(all.size(), std::size_t{9});
+        for (std::size_t i = 0; i < at.size(); ++i) {
+            auto resumed = get_matcher();
+            spm::restore(resumed, at[i].second);
+            sequence_t rest{haystack.begin() + at[i].first, haystack.end()};
+            std::vector<std::size_t> got{};
+            resumed(rest, [&](auto const & finder) { got.push_back(seqan2::endPosition(finder) + at[i].first); });
+            EXPECT_TRUE(std::ranges::equal(got, std::vector<std::size_t>(all.begin() + i + 1, all.end())));
+        }
+        // the state after the call is the state after the last symbol, whatever was captured on the way
+        auto plain = get_matcher();
+        plain(haystack, [](auto const &) {});
+        EXPECT_TRUE(spm::capture(matcher) == spm::capture(plain));
+    }
+    { // restore() inside a callback: the rest of the chunk continues from the restored state.  Restoring the
+      // constructor-time state at the 2nd hit (end 14 = the exact occurrence) makes the matcher forget the symbols read
+      // so far: the hit at 15 (one deletion, needs the occurrence's prefix) disappears, the later occurrences stay
+        auto matcher = get_matcher();
+        auto const fresh = spm::capture(matcher);
+        std::vector<std::size_t> got{};
+        int seen = 0;
+        matcher(haystack, [&](auto const & finder) {
+            got.push_back(seqan2::endPosition(finder));
+            if (++seen == 2)
+                spm::restore(matcher, fresh);
+        });
+        EXPECT_TRUE(std::ranges::equal(got, std::vector<std::size_t>{13, 14, 24, 25, 26, 35, 36, 37}));
+        // ... which is what two separate scans of the two parts give
+        auto a = get_matcher(), b = get_matcher();
+        std::vector<std::size_t> two{};
+        sequence_t const part1{haystack.begin(), haystack.begin() + 14}, part2{haystack.begin() + 14, haystack.end()};
+        a(part1, [&](auto const & f) { two.push_back(seqan2::endPosition(f)); });
+        b(part2, [&](auto const & f) { two.push_back(seqan2::endPosition(f) + 14); });
+        EXPECT_TRUE(std::ranges::equal(got, two));
+    }
+    { // more hits than the default device hit buffer (2^20): |P| = 5, k = 1 on 3 Mbases of ACGT..: no limit, no abort
+        std::size_t const n = 3u << 20;
+        sequence_t big(n);
+        for (std::size_t i = 0; i < n; ++i)
+            big[i] = spm::dna4{static_cast<std::uint8_t>(i & 3)};
+        sequence_t const short_needle = "ACGTA"_dna4;
+        auto matcher = spm::myers_matcher{short_needle, 1};
+        std::size_t hits = 0, last = 0;
+        bool ascending = true;
+        matcher(big, [&](auto const & finder) {
+            ascending = ascending && seqan2::endPosition(finder) >= last;
+            last = seqan2::endPosition(finder);
+            ++hits;
+        });
+        EXPECT_TRUE(hits > (1u << 21)); // every position from the 4th on ends an occurrence with <= 1 error
+        EXPECT_TRUE(ascending);
+        EXPECT_EQ(last, n);
+        // the pigeonhole matcher: every window of 8 symbols with the right phase is a seed hit
+        std::vector<sequence_t> seeds{"ACGTACGT"_dna4};
+        auto pm = spm::pigeonhole_matcher{seeds, 0.0};
+        std::size_t seed_hits = 0;
+        pm(big, [&](auto const &) { ++seed_hits; });
+        EXPECT_EQ(seed_hits, (n - 8) / 4 + 1);
+    }
+}
+
 int main()
 {
     horspool_cases();
@@ -363,6 +440,7 @@ int main()
     batch_cases();
     alphabet_cases();
     container_adapter_cases();
+    paused_scan_cases();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures;
 }
