@@ -139,17 +139,22 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
     st = jst.index(window, 1024)
     max_hits = 1 << 23
     cap = max_hits
-    hit_buf = torch.zeros((cap, 3), dtype=torch.int64, device=dev)
+    og = sdist.OverlappedGather(dev, cap, 3)   # N > 1: the records of search i travel while search i + 1 runs
+    n_step = [0]
 
     def step():
+        i = n_step[0]
+        n_step[0] += 1
+        buf = og.buffer(i)
         h = jst.search_device(ps, engine=engine, max_hits=max_hits)
-        n = h.copy_to(hit_buf.data_ptr(), cap)
-        gathered = sdist.gatherv_hits(hit_buf[:n])      # rank 0: every rank's records, rank order
+        n = h.copy_to(buf.data_ptr(), cap)
+        gathered = og.submit(i, n)                  # rank 0: every rank's records, rank order
         return h, gathered, n
 
     for _ in range(args.warmup):
         h, g, n = step()
         h.close()
+    og.finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -167,6 +172,7 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
         if last is not None:
             last[0].close()
         last = (h, g, n, s1)
+    og.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -220,7 +226,9 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
                    "reference_bases_per_gpu": ref_len, "alleles_per_gpu": int(len(alleles)), "block_len": 1024,
                    "engine": engine_used,
                    "sharding": (f"one reference chromosome per GPU, {world} GPUs; hit records gathered to rank 0 "
-                                "(count all-gather + grouped send/recv)") if world > 1 else "single GPU"},
+                                "(count all-gather + grouped send/recv on a side stream: the records of search i "
+                                "travel while search i + 1 runs)") if world > 1 else "single GPU",
+                   "exchange_bytes_per_rank_and_step": int(n_local) * 24},
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,

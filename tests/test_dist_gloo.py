@@ -32,6 +32,17 @@ def _worker(rank, world, port, counts, q):
         # 24-byte journaled-sequence hit records (three int64 words) go through the same gatherv
         wide = torch.cat([local, (local[:, :1] * 3 + 1)], dim=1)
         out3 = sdist.gatherv_hits(wide, dst=0)
+        # the double-buffered variant bench.py uses for C5 (on CPU tensors it degenerates to the plain gatherv)
+        og = sdist.OverlappedGather(torch.device("cpu"), 16, 2)
+        outs = []
+        for i in range(3):
+            buf = og.buffer(i)
+            buf[:n] = local + i
+            outs.append(og.submit(i, n))
+        og.finish()
+        if rank == 0:
+            for i in range(3):
+                assert torch.equal(outs[i], out + i)
         if rank == 0:
             assert torch.equal(fused, out)
             assert out3.shape[1] == 3 and torch.equal(out3[:, :2], out) and torch.equal(out3[:, 2], out[:, 0] * 3 + 1)
