@@ -275,6 +275,7 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
     """The oracle (CPU restatement of the reference path: one matcher per needle, one pass per matcher) timed on
     the host cores, on a bounded sample of the same workload.  A reported baseline, not the target."""
     from oracle import oracle as O
+    native = O.use_native_build()  # -O3 -march=native on this host (oracle/Makefile, target `native`)
     cores = max(1, min(os.cpu_count() or 1, 64))
     o_algo = O.MYERS if algo == "myers" else O.SHIFTOR
     pats = [O.pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(64)]
@@ -298,6 +299,12 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
         "cores": cores,
         "kind": "port",
         "lane_steps_per_s": lane_steps,
+        # one needle, one thread, one symbol: the serial VP/VN dependency chain of the bit-vector recurrence
+        "ns_per_symbol_step_per_thread": 1e9 / rate1,
+        "ns_per_symbol_step_per_thread_all_cores_busy": cores * 1e9 / lane_steps,
+        "build": "-O3 -march=native" if native else "-O3 (portable build; the native rebuild failed)",
+        "loop": "two 64-bit blocks with Ukkonen cut-off, state in registers (oracle/spm_oracle.c: "
+                "spm_oracle_myers2_fast)" if algo == "myers" and 64 < L <= 128 else "generic block loop",
         "sample": f"64 needles x {n_sample / 2**20:.0f} MiB of the same synthetic text, one sequential pass per "
                   f"needle over {cores} threads, best of 2; value = measured lane-steps/s / {n_pat_full} needles "
                   f"(linear extrapolation to the full needle set); {len(hits)} hits",

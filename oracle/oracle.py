@@ -38,6 +38,20 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_native_build() -> bool:
+    """bench.py's cpu_baseline leg: rebuild the library for THIS machine's CPU (-march=native) and load that copy, so the
+    timed loop is what a local build of the reference would get.  Falls back to the portable build (False)."""
+    global _SO, _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _SO = os.path.join(_HERE, "libspm_oracle_native.so")
+    _lib = None
+    return True
+
+
 _lib = None
 
 
@@ -60,6 +74,9 @@ def lib():
         L.spm_oracle_myers_scan.restype = C.c_size_t
         L.spm_oracle_myers_scan.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int,
                                             C.c_int, C.POINTER(MyersState), C.c_uint64, C.c_void_p, C.c_size_t]
+        L.spm_oracle_myers2_fast.restype = C.c_size_t
+        L.spm_oracle_myers2_fast.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
+                                             C.c_void_p, C.c_size_t]
         L.spm_oracle_sellers.restype = C.c_size_t
         L.spm_oracle_sellers.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p,
                                          C.c_uint64, C.c_void_p, C.c_size_t]
@@ -146,6 +163,17 @@ def myers(text, pat, k, sigma=4, mode=INFIX, variant=None, state=None, text_offs
     out = np.zeros(cap, dtype=HIT_DTYPE)
     n = lib().spm_oracle_myers_scan(tp, len(t), pp, m, sigma, k, mode, variant, C.byref(state), text_offset,
                                     out.ctypes.data, cap)
+    return out[:n].copy()
+
+
+def myers2_fast(text, pat, k, sigma=4, text_offset=0):
+    """The two-block register loop the CPU baseline times (64 < |P| <= 128)."""
+    t, tp = _u8(text)
+    p, pp = _u8(pat)
+    cap = len(t) + 1
+    out = np.zeros(cap, dtype=HIT_DTYPE)
+    n = lib().spm_oracle_myers2_fast(tp, len(t), pp, len(p), sigma, k, text_offset, out.ctypes.data, cap)
+    assert n != 2**64 - 1
     return out[:n].copy()
 
 

@@ -283,6 +283,78 @@ size_t spm_oracle_myers_scan(const uint8_t *text, size_t n, const uint8_t *pat, 
     return cnt;
 }
 
+/* The same scan as variant 2 (blocks with Ukkonen cut-off, infix mode, fresh matcher) for 64 < m <= 128, everything in
+ * registers: the loop the CPU baseline times.  [upstream] _findMyersLargePatterns keeps its state in a heap object and
+ * loops over lastBlock+1 blocks; for two blocks that is this code.  On text without near-occurrences only block 0 is
+ * inside the band, so a symbol costs one 64-bit word step (~1 ns), which is what SURVEY 8(a)-a5 quotes for SeqAn.
+ * tests/test_oracle_golden.py checks it hit for hit against variant 2 and against Sellers. */
+size_t spm_oracle_myers2_fast(const uint8_t *text, size_t n, const uint8_t *pat, size_t m, uint32_t sigma, uint32_t k,
+                              uint64_t text_offset, spm_oracle_hit *out, size_t cap)
+{
+    if (m <= 64 || m > 128)
+        return (size_t)-1;
+    uint64_t peq0[256], peq1[256];
+    memset(peq0, 0, sizeof(peq0));
+    memset(peq1, 0, sizeof(peq1));
+    for (size_t j = 0; j < m; ++j)
+        if (pat[j] < sigma) {
+            if (j < 64)
+                peq0[pat[j]] |= 1ull << j;
+            else
+                peq1[pat[j]] |= 1ull << (j - 64);
+        }
+    const int32_t kk = (int32_t)k;
+    const int32_t rows1 = (int32_t)(m - 64);
+    const uint32_t top1 = (uint32_t)(m - 65); /* bit of the needle's last row inside block 1 */
+    uint64_t VP0 = ~0ull, VN0 = 0, VP1 = ~0ull, VN1 = 0;
+    int32_t s0 = 64, s1 = (int32_t)m; /* D at the bottom row of block 0 / block 1 */
+    int two = kk >= 64;               /* is block 1 inside the band? */
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t c = text[i] < sigma ? text[i] : 255; /* row 255 of the tables stays empty for sigma <= 255 */
+        if (!two && s0 <= kk) { /* band grows (see variant 2) */
+            VP1 = ~0ull;
+            VN1 = 0;
+            s1 = s0 + rows1;
+            two = 1;
+        }
+        uint64_t X = peq0[c] | VN0;
+        const uint64_t sum0 = VP0 + (X & VP0);
+        const uint64_t carry = sum0 < VP0;
+        uint64_t D0 = (sum0 ^ VP0) | X;
+        uint64_t HN = VP0 & D0;
+        uint64_t HP = VN0 | ~(VP0 | D0);
+        s0 += (int32_t)(HP >> 63) - (int32_t)(HN >> 63);
+        const uint64_t cHP = HP >> 63, cHN = HN >> 63;
+        X = HP << 1;
+        VN0 = X & D0;
+        VP0 = (HN << 1) | ~(X | D0);
+        if (two) {
+            X = peq1[c] | VN1;
+            const uint64_t t = X & VP1;
+            const uint64_t sum1 = VP1 + t + carry;
+            D0 = (sum1 ^ VP1) | X;
+            HN = VP1 & D0;
+            HP = VN1 | ~(VP1 | D0);
+            s1 += (int32_t)((HP >> top1) & 1) - (int32_t)((HN >> top1) & 1);
+            X = (HP << 1) | cHP;
+            VN1 = X & D0;
+            VP1 = ((HN << 1) | cHN) | ~(X | D0);
+            if (s1 <= kk) {
+                if (cnt < cap) {
+                    out[cnt].pos = text_offset + i + 1;
+                    out[cnt].pattern = 0;
+                    out[cnt].score = s1;
+                }
+                ++cnt;
+            }
+            if (s1 >= kk + rows1) /* band shrinks: the whole of block 1 is > k */
+                two = 0;
+        }
+    }
+    return cnt;
+}
+
 size_t spm_oracle_sellers(const uint8_t *text, size_t n, const uint8_t *pat, size_t m, uint32_t k, int mode,
                           int32_t *col, uint64_t text_offset, spm_oracle_hit *out, size_t cap)
 {
@@ -463,7 +535,9 @@ static void *multi_worker(void *arg)
         const uint8_t *pat = J->pats + J->offsets[p];
         size_t m = J->offsets[p + 1] - J->offsets[p];
         size_t c = 0;
-        if (J->algo == 1) {
+        if (J->algo == 1 && m > 64 && m <= 128) {
+            c = spm_oracle_myers2_fast(J->text, J->n, pat, m, J->sigma, J->k, 0, tmp, tmp_cap);
+        } else if (J->algo == 1) {
             spm_oracle_myers_state st;
             spm_oracle_myers_init(&st, m, J->k, m > 64);
             c = spm_oracle_myers_scan(J->text, J->n, pat, m, J->sigma, J->k, SPM_ORACLE_INFIX, m > 64 ? 2 : 0,

@@ -91,6 +91,11 @@ size_t spm_oracle_myers_scan(const uint8_t *text, size_t n, const uint8_t *pat, 
                              uint32_t k, int mode, int variant, spm_oracle_myers_state *st,
                              uint64_t text_offset, spm_oracle_hit *out, size_t cap);
 
+/* Variant 2 for 64 < m <= 128 (two blocks), fresh matcher, infix mode, all state in registers: the loop the CPU baseline
+ * times.  Returns (size_t)-1 for other lengths. */
+size_t spm_oracle_myers2_fast(const uint8_t *text, size_t n, const uint8_t *pat, size_t m, uint32_t sigma, uint32_t k,
+                              uint64_t text_offset, spm_oracle_hit *out, size_t cap);
+
 /* Sellers O(nm) DP -- the definition.  col: m+1 ints carried across chunks (NULL = fresh). */
 size_t spm_oracle_sellers(const uint8_t *text, size_t n, const uint8_t *pat, size_t m, uint32_t k, int mode,
                           int32_t *col, uint64_t text_offset, spm_oracle_hit *out, size_t cap);

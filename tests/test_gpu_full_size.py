@@ -118,3 +118,105 @@ def test_full_size_properties(spm, ctx, oracle, name):
     whole.close()
     ps.close()
     text.close()
+
+
+def _edit_needle(spm, src, L, e, seed):
+    """bench.py's needle maker: e edits at pseudo-random places of a haplotype window (substitute / delete / insert)."""
+    mix = spm.capi.lib().spm_hip_mix64
+    out = [int(x) for x in src[:L + e]]
+    for j in range(e):
+        r = mix(seed + j + 1)
+        at, kind = r % L, (r >> 32) % 3
+        if kind == 0:
+            out[at] = (out[at] + 1 + (r >> 40) % 3) & 3
+        elif kind == 1:
+            del out[at]
+        else:
+            out.insert(at, (r >> 40) & 3)
+    return np.array(out[:L], dtype=np.uint8)
+
+
+def test_full_size_c5_journaled_pan_genome(spm, ctx, oracle):
+    """C5 at its bench size -- 2^27-base reference x 64 haplotypes (8.56 Gbases of haplotype sequence), 256 needles
+    |P| = 1024, k <= 64 -- where per-haplotype scans of everything are out of reach:
+
+      * every planted needle is reported on the haplotype it was cut from, where it was cut, with <= its planted edits
+      * records sorted by (haplotype, pos, pattern), no duplicates
+      * soundness + completeness on coordinate sub-ranges of three haplotypes: the device search's records there ==
+        an ordinary scan of the extracted haplotype stretch == the oracle's hit list (one pass per needle)
+      * the union of two block shards of the tree (one GPU each in the N > 1 run) == the whole search
+    """
+    O = oracle
+    SEED_VAR = 0x5EED0003
+    L, kmax, n_pat, n_hap = 1024, 64, 256, 64
+    ref_len = (1 << 27) // 640000 * 640000
+    mix = spm.capi.lib().spm_hip_mix64
+    ref = ctx.generate(SEED_TEXT, 0, ref_len)
+    alleles, pool, cov = spm.synth_variants(SEED_TEXT, SEED_VAR, 0, ref_len, n_hap)
+    jst = spm.Jst(ctx, ref, alleles, pool, cov.reshape(-1, 1), n_hap)
+    window = L + kmax
+    needles, planted = [], []
+    for p in range(n_pat):
+        r = mix(SEED_PAT + 7919 * p)
+        h = r % n_hap
+        o = (r >> 8) % (jst.haplotype_length(h) - 2 * window)
+        e = p % (kmax + 1)
+        needles.append(_edit_needle(spm, jst.extract(h, o, window), L, e, SEED_PAT ^ (p << 20)))
+        planted.append((h, o, e))
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=kmax)
+    assert ps.filterable
+    st = jst.index(window, 1024)
+    assert st.haplotype_symbols > 8.5e9 and st.context_symbols < st.haplotype_symbols / 4
+    rec = jst.search(ps, max_hits=1 << 23)
+    js = jst.stats()
+    assert js.engine_used == spm.ENGINE_FILTER and js.fell_back == 0
+    assert len(rec) > 500_000
+
+    # sorted, unique
+    key = np.stack([rec["haplotype"].astype(np.int64), rec["pos"].astype(np.int64), rec["pattern"].astype(np.int64)], 1)
+    d = np.diff(key, axis=0)
+    lex_up = (d[:, 0] > 0) | ((d[:, 0] == 0) & ((d[:, 1] > 0) | ((d[:, 1] == 0) & (d[:, 2] > 0))))
+    assert lex_up.all()
+
+    # planted needles
+    for p, (h, o, e) in enumerate(planted):
+        m = (rec["pattern"] == p) & (rec["haplotype"] == h)
+        assert np.any((np.abs(rec["pos"][m].astype(np.int64) - (o + L)) <= kmax) & (rec["score"][m] <= e)), (p, h, o, e)
+
+    # sub-ranges of three haplotypes: around two planted sites each + one anywhere
+    rng = np.random.default_rng(11)
+    sub = 1 << 16
+    for h in (0, 17, 63):
+        hl = jst.haplotype_length(h)
+        sites = [o for (hh, o, e) in planted if hh == h][:2] + [int(rng.integers(0, hl - sub))]
+        for s in sites:
+            s = max(0, min(int(s) - sub // 2, hl - sub))
+            a = max(0, s - (window - 1))
+            frag = jst.extract(h, a, s + sub - a)
+            owned_lo, owned_hi = s + 1, s + sub + 1          # exclusive end positions owned by [s, s + sub)
+            m = (rec["haplotype"] == h) & (rec["pos"].astype(np.int64) >= owned_lo) & (rec["pos"].astype(np.int64) < owned_hi)
+            got = sorted(zip(rec["pattern"][m].tolist(), rec["pos"][m].astype(np.int64).tolist(), rec["score"][m].tolist()))
+            t = ctx.upload(frag)
+            v = spm.scan(ctx, t, ps, max_hits=1 << 20).view()
+            t.close()
+            pos = v["pos"].astype(np.int64) + a
+            keep = (pos >= owned_lo) & (pos < owned_hi)
+            direct = sorted(zip(v["pattern"][keep].tolist(), pos[keep].tolist(), v["score"][keep].tolist()))
+            assert got == direct, (h, s, len(got), len(direct))
+            o_ref = O.scan_multi(O.MYERS, frag, needles, k=kmax, threads=16, cap=1 << 20)
+            opos = o_ref["pos"].astype(np.int64) + a
+            ok = (opos >= owned_lo) & (opos < owned_hi)
+            want = sorted(zip(o_ref["pattern"][ok].tolist(), opos[ok].tolist(), o_ref["score"][ok].tolist()))
+            assert got == want, (h, s, len(got), len(want))
+
+    # block shards (SURVEY 8(e)): two halves of the tree == the whole
+    nb = int(st.n_blocks)
+    parts = []
+    for b0, b1 in ((0, nb // 2), (nb // 2, nb)):
+        jst.index(window, 1024, b0, b1)
+        parts.append(jst.search(ps, max_hits=1 << 23))
+    both = np.sort(np.concatenate(parts), order=["haplotype", "pos", "pattern", "score"])
+    assert np.array_equal(both, np.sort(rec, order=["haplotype", "pos", "pattern", "score"]))
+    jst.close()
+    ps.close()
+    ref.close()

@@ -162,3 +162,36 @@ def test_checksum_is_order_independent(oracle):
     h["score"] = [0, 3, 1, 2, 0]
     assert O.checksum(h) == O.checksum(h[::-1].copy())
     assert O.checksum(h) != O.checksum(h[:4])
+
+
+def test_two_block_register_loop_equals_block_variant_and_sellers(oracle):
+    """The loop the CPU baseline times (spm_oracle_myers2_fast) == variant 2 (blocks + cut-off) == Sellers, hit for hit:
+    |P| in 65..128, k up to 70, texts with planted near-occurrences (the band grows and shrinks) and low-complexity runs."""
+    O = oracle
+    rng = np.random.default_rng(3)
+    for m, k in [(65, 0), (65, 3), (100, 3), (100, 1), (127, 5), (128, 3), (128, 12), (96, 40), (100, 70)]:
+        n = 6000
+        T = rng.integers(0, 4, n, dtype=np.uint8)
+        P = rng.integers(0, 4, m, dtype=np.uint8)
+        for at, edits in ((500, 0), (1500, min(k, 2)), (2500, k), (3500, k + 1)):
+            occ = P.copy()
+            for e in range(edits):
+                occ[(7 * e + 3) % m] ^= 1
+            T[at:at + m] = occ
+        T[4000:4300] = 0
+        T[4300:4300 + min(m, 100)] = P[:100]
+        got = O.myers2_fast(T, P, k)
+        ref = O.myers(T, P, k, variant=2)
+        sel = O.sellers(T, P, k)
+        assert np.array_equal(got["pos"], ref["pos"]) and np.array_equal(got["score"], ref["score"]), (m, k)
+        assert np.array_equal(got["pos"], sel["pos"]) and np.array_equal(got["score"], sel["score"]), (m, k)
+        assert len(got) >= 1
+    # the multi-needle driver takes this loop for two-block needles: same list as one variant-2 pass per needle
+    T = O.text(0x5EED0001, 0, 1 << 16)
+    needles = [O.pattern(0x5EED0001, 0x5EED0002, 1 << 16, p, 100, 3)[0] for p in range(12)]
+    multi = O.scan_multi(O.MYERS, T, needles, k=3, threads=3)
+    one = []
+    for p, nd in enumerate(needles):
+        r = O.myers(T, nd, 3, variant=2)
+        one += [(p, int(a), int(b)) for a, b in zip(r["pos"], r["score"])]
+    assert sorted(zip(multi["pattern"].tolist(), multi["pos"].tolist(), multi["score"].tolist())) == sorted(one)
