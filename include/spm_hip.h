@@ -113,7 +113,9 @@ int spm_hip_synchronize(spm_ctx *ctx);
 /* ---- haystack: replaces spm::make_seqan_container(views::all(haystack)), seqan_pattern_base.hpp:44-45 ----
  * sigma = alphabet size (4 dna4, 5 dna5, 15 dna15; seqan/alphabet.hpp:100-105); symbols are ranks < sigma. */
 int spm_hip_text_upload(spm_ctx *ctx, const uint8_t *ranks, uint64_t n, uint32_t sigma, spm_text **out);
-/* Borrow a device buffer (16-byte aligned) that the caller keeps alive, e.g. a torch uint8 tensor. */
+/* Borrow a device buffer (16-byte aligned) that the caller keeps alive, e.g. a torch uint8 tensor.  The buffer is read
+ * once (at HBM speed) to check that every symbol is a rank < sigma; SPM_E_INVALID otherwise -- the same contract as
+ * spm_hip_text_upload.  The caller must not change it while the handle lives. */
 int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_t n, uint32_t sigma, spm_text **out);
 /* Synthetic uniform dna4 text generated in HBM: base(i) of SURVEY.md 8(d) for i in [global_begin, +n). */
 int spm_hip_text_generate(spm_ctx *ctx, uint64_t seed, uint64_t global_begin, uint64_t n, spm_text **out);

@@ -663,6 +663,28 @@ __global__ __launch_bounds__(256) void text_pack_kernel(const uint8_t *__restric
         atomicOr(bad, 1u);
 }
 
+// A borrowed haystack (spm_hip_text_wrap) is read once to make sure every symbol is a rank < sigma: the filter's 2-bit
+// packing would fold a stray byte into its neighbours' codes and could then miss an occurrence the brute-force engine
+// reports.
+__global__ __launch_bounds__(256) void text_validate_kernel(const uint8_t *__restrict__ text, uint64_t n, uint32_t sigma,
+                                                            unsigned int *bad)
+{
+    const uint64_t n_q = (n + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned int any_bad = 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += stride) {
+        const uint4 v = load_text16(text, q * 16, n); // bytes past n read as 0
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                any_bad |= ((w[i] >> (8 * b)) & 0xFFu) >= sigma ? 1u : 0u;
+    }
+    if (any_bad)
+        atomicOr(bad, 1u);
+}
+
 // Same filter, fed from the shadow: one 16-byte load per lane = 4 words = 64 symbols; a wave-load ("p-chunk") covers
 // 4096 symbols.  U2 p-chunks per group, the next group's loads in flight.  The shadow is zero-padded to whole
 // p-chunks, so every load is unconditional; windows reaching past the text are dropped by the range check.

@@ -860,6 +860,25 @@ extern "C" int spm_hip_text_wrap(spm_ctx *ctx, const void *device_ranks, uint64_
         SPM_SET_ERR(ctx, "spm_hip_text_wrap: invalid argument (pointer must be 16-byte aligned)");
         return SPM_E_INVALID;
     }
+    if (n) { // one pass over the borrowed buffer: every symbol must be a rank < sigma (as spm_hip_text_upload checks)
+        SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        unsigned int *d_bad = nullptr;
+        dev_scratch tmp;
+        SPM_HIP_CHECK(ctx, tmp.alloc(&d_bad, sizeof(unsigned int)));
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_bad, 0, sizeof(unsigned int), ctx->stream));
+        const uint64_t n_q = (n + 15) / 16;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_q + 255) / 256, (uint64_t)ctx->n_cu * 16);
+        hipLaunchKernelGGL(text_validate_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t *)device_ranks, n,
+                           sigma, d_bad);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        unsigned int bad = 0;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) {
+            SPM_SET_ERR(ctx, "spm_hip_text_wrap: the buffer holds symbols that are not ranks < sigma=%u", sigma);
+            return SPM_E_INVALID;
+        }
+    }
     spm_text *t = new spm_text;
     t->ctx = ctx;
     t->d = (uint8_t *)device_ranks;

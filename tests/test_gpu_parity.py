@@ -690,10 +690,17 @@ def test_pack_rejects_non_dna4(spm, ctx, oracle):
     with pytest.raises(spm.SpmError):
         t5.pack()
     import torch
-    bad = torch.full((4096,), 7, dtype=torch.uint8, device="cuda")
-    tw = ctx.wrap(bad.data_ptr(), 4096, sigma=4, keepalive=bad)
-    with pytest.raises(spm.SpmError):
-        tw.pack()
+    # a borrowed buffer is validated when it is wrapped (a stray byte would corrupt the filter's 2-bit packing)
+    bad = torch.zeros((1 << 20,), dtype=torch.uint8, device="cuda")
+    ok = ctx.wrap(bad.data_ptr(), bad.numel(), sigma=4, keepalive=bad)
+    assert len(ok) == bad.numel()
+    bad[777_777] = 7
+    torch.cuda.synchronize()
+    with pytest.raises(spm.SpmError, match="not ranks"):
+        ctx.wrap(bad.data_ptr(), bad.numel(), sigma=4, keepalive=bad)
+    with pytest.raises(spm.SpmError, match="not ranks"):
+        ctx.wrap(bad.data_ptr(), bad.numel(), sigma=5, keepalive=bad)
+    assert len(ctx.wrap(bad.data_ptr(), bad.numel(), sigma=15, keepalive=bad)) == bad.numel()
 
 
 def test_c_abi_error_paths(spm, ctx, oracle):
