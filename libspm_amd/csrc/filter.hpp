@@ -38,7 +38,12 @@ namespace spm_hip
 {
 
 constexpr uint32_t kKeyMax = 16; // symbols per key: 16 whenever the seeds allow it, down to kKeyMin for short seeds
-constexpr uint32_t kKeyMin = 12;
+// Short keys match by chance (windows x keys / 4^H survivors).  The streaming kernel only records a survivor (16 bytes)
+// and resolve_kernel disposes of it in ~0.2 ns of GPU time, so keys down to 9 symbols pay: |P| = 32, k = 2 (seeds of 10)
+// with 1000 needles leaves 0.3 % of the windows -- against a ~3000x slower brute-force scan.  A set whose keys would let
+// more than kMaxSurvivorShare of all windows through stays with the brute-force engine.
+constexpr uint32_t kKeyMin = 9;
+constexpr double kMaxSurvivorShare = 0.08;
 
 // Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
 // needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
@@ -220,6 +225,42 @@ __device__ __forceinline__ uint32_t pack16_dna5(const uint4 v, uint32_t &nmask)
     return code;
 }
 
+// dna15 haystacks (seqan3 ranks A0 B1 C2 D3 G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T -> 0..3, every
+// ambiguity code marked like dna5's N (a window that holds one equals no key).  SWAR on the four bytes of a dword:
+// a key symbol is T (11) or an even rank <= 4; its code is rank >> 1 (T: 3).  ~14 VALU per dword.
+__device__ __forceinline__ uint32_t pack16_dna15(const uint4 v, uint32_t &nmask)
+{
+    const uint32_t W = 0x40100401u, WN = 0x08040201u;
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t code = 0;
+    nmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = x[i] ^ 0x0B0B0B0Bu;                                          // byte == 11 <=> zero byte
+        const uint32_t isT = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu) >> 7; // exact per-byte zero test
+        const uint32_t odd = x[i] & 0x01010101u;
+        const uint32_t big = ((x[i] + 0x7B7B7B7Bu) & 0x80808080u) >> 7;                   // byte >= 5
+        const uint32_t amb = (odd | big) & ~isT;
+        const uint32_t c2 = (((x[i] >> 1) & 0x03030303u) & ~(isT * 3u)) | (isT * 3u);
+        code |= __builtin_amdgcn_udot4(c2 & ~(amb * 3u), W, 0u, false) << (8 * i);
+        nmask |= __builtin_amdgcn_udot4(amb, WN, 0u, false) << (4 * i);
+    }
+    return code;
+}
+
+template <int SIG>
+__device__ __forceinline__ uint32_t pack16_sig(const uint4 v, uint32_t &nmask)
+{
+    if constexpr (SIG == 5)
+        return pack16_dna5(v, nmask);
+    else if constexpr (SIG == 15)
+        return pack16_dna15(v, nmask);
+    else {
+        nmask = 0;
+        return pack16(v);
+    }
+}
+
 __device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, uint64_t limit)
 {
     // idx % 16 == 0.  Bytes at or beyond `limit` read as 0.
@@ -364,7 +405,7 @@ __device__ __forceinline__ void emit_survivors(const filter_params &P, bool has,
 // KM: keys shorter than 16 symbols (masked); only strides 1 and 2 ever carry such keys.
 template <int S, int NWD, int HV, int SIG, bool PK, bool KM>
 __device__ __forceinline__ void filter_words(const filter_params &P, const uint32_t (&w)[NWD],
-                                             const uint32_t (&prev)[NWD], const uint32_t (&nv)[SIG == 5 ? NWD : 1],
+                                             const uint32_t (&prev)[NWD], const uint32_t (&nv)[SIG != 4 ? NWD : 1],
                                              uint64_t gbase, uint32_t lane, const uint32_t *lds, uint32_t idx_mask)
 {
     constexpr int NWIN = 16 / S; // windows per word
@@ -443,7 +484,7 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
             pos_mask = keep;
         }
     }
-    if constexpr (SIG == 5) {
+    if constexpr (SIG != 4) {
         if (__ballot(pos_mask != 0) != 0) {
 #pragma unroll
             for (int u = 0; u < NWD; ++u) {
@@ -499,16 +540,16 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
                                              const uint32_t *lds, uint32_t idx_mask)
 {
     uint32_t w[UU], prev[UU];
-    uint32_t nv[SIG == 5 ? UU : 1]; // dna5: (this lane's N mask << 16) | previous lane's N mask
+    uint32_t nv[SIG != 4 ? UU : 1]; // dna5 / dna15: (this lane's N mask << 16) | previous lane's N mask
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         uint32_t nm = 0;
-        w[u] = SIG == 5 ? pack16_dna5(cur[u], nm) : pack16(cur[u]);
+        w[u] = pack16_sig<SIG>(cur[u], nm);
         prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
         if (lane == 0)
             prev[u] = carry_in;
         carry_in = __builtin_amdgcn_readlane(w[u], 63);
-        if (SIG == 5) {
+        if (SIG != 4) {
             uint32_t np = __builtin_amdgcn_update_dpp(0u, nm, 0x138, 0xF, 0xF, false);
             if (lane == 0)
                 np = carry_n;
@@ -597,7 +638,7 @@ __global__ __launch_bounds__((S == 1 && !KM && SIG == 4) ? 1024 : 512) void seed
             const uint64_t cb = base0 + c_begin * 1024;
             if (cb >= 16 && lane == 0) {
                 const uint4 before = load_text16(P.text, cb - 16, P.hi);
-                carry_in = SIG == 5 ? pack16_dna5(before, carry_n) : pack16(before);
+                carry_in = pack16_sig<SIG>(before, carry_n);
             }
             carry_in = __builtin_amdgcn_readfirstlane(carry_in);
             carry_n = __builtin_amdgcn_readfirstlane(carry_n);
@@ -866,6 +907,7 @@ struct resolve_params
     uint64_t text_alloc;            // readable bytes from text
     const uint8_t *needle_ranks;    // the needles' symbols back to back, padded (nullptr: no whole-seed check)
     const uint32_t *needle_offsets; // start of every needle in needle_ranks
+    const uint16_t *seed_q;         // seed length of every needle
     const int32_t *m, *k;
     uint64_t hay_begin, hay_end;    // unsegmented scans: the haystack
     const uint64_t *seg_offsets;
@@ -914,14 +956,19 @@ __device__ __forceinline__ uint32_t diff16(const uint4 a, const uint4 b, uint32_
     return r;
 }
 
-__device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t, uint32_t val, int64_t hay_b, int64_t hay_e)
+// r = offset of the key window inside its seed (the seeds of a needle with an N do not sit at multiples of q)
+__device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t, uint32_t val, uint32_t r, int64_t hay_b,
+                                            int64_t hay_e)
 {
     if (!P.needle_ranks)
         return true;
     const uint32_t pat = val >> 11, x = val & 0x7FF;
-    const seed_plan sp = plan_seeds((uint32_t)P.m[pat], (uint32_t)P.k[pat]);
-    const uint32_t o = (x / sp.q) * sp.q; // start of the seed inside the needle
-    const int64_t ts = (int64_t)t - (int64_t)(x - o); // where the seed would start in the text
+    struct
+    {
+        uint32_t q;
+    } sp{P.seed_q[pat]};
+    const uint32_t o = x - r; // start of the seed inside the needle
+    const int64_t ts = (int64_t)t - (int64_t)r; // where the seed would start in the text
     if (ts < hay_b || ts + (int64_t)sp.q > hay_e)
         return false; // it would stick out of the haystack
     const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat] + o; // (the needle buffer is padded: no guard)
@@ -1058,7 +1105,7 @@ __device__ __forceinline__ void resolve_pairs(const resolve_params &R, const pai
         }
     }
     if (emit && !(rng & kRngRun) &&
-        !(((rng & kSeedChecked) || seed_intact(R, t, val, sb, se)) && pieces_plausible(R, t, val, sb, se)))
+        !(((rng & kSeedChecked) || seed_intact(R, t, val, (rng >> 16) & 0xF, sb, se)) && pieces_plausible(R, t, val, sb, se)))
         emit = false;
     // bands this pair counts into: those holding a diagonal of [d_lo, d_hi]; with overlapping bands also the one
     // before, if d_lo still lies in its k-wide extension
@@ -1246,7 +1293,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                         if (!(rng & kRngRun)) {
                             const uint32_t r0 = rng & 0xF, ns = (rng >> 4) & 0x1F;
                             const bool whole = (rng & kRngWhole) != 0;
-                            rng = 0;
+                            rng = r0 << 16; // (queued with the pair: where the key window sits in its seed)
                             if (W.ok) { // does the rest of the seed match?  (registers only)
                                 if (!seed_sig_ok(W, e.z, r0, ns, R.key_len))
                                     have = false;

@@ -81,6 +81,10 @@ struct spm_patterns
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
     uint32_t filter_max_range = 0; // largest diagonal range over all passes
+    // seed layout (filterable sets): needle p has seed_n[p] seeds of seed_q[p] symbols at seed_off[seed_first[p] + j]
+    std::vector<uint16_t> seed_q, seed_n, seed_off;
+    std::vector<uint32_t> seed_first;
+    uint16_t *d_seed_q = nullptr;
     pass_entry *d_pass_tab = nullptr; // the passes' exact key tables, for resolve_kernel
     mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
     mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
@@ -103,6 +107,72 @@ static int env_int(const char *name, int dflt)
 static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
                            filter_index &F);
 
+// A symbol the 2-bit keys can hold: A, C, G, T.  dna5 (seqan3 ranks A0 C1 G2 N3 T4): everything but N; dna15 (A0 B1 C2 D3
+// G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T only.
+static inline bool key_symbol(uint32_t sigma, uint8_t c)
+{
+    return sigma == 4 ? c < 4 : sigma == 5 ? (c < 5 && c != 3) : (c == 0 || c == 2 || c == 4 || c == 11);
+}
+static inline uint32_t key_code(uint32_t sigma, uint8_t c) // 2-bit code of a key symbol
+{
+    return sigma == 4 ? (c & 3u) : sigma == 5 ? (c == 4 ? 3u : c) : (c == 11 ? 3u : (uint32_t)c >> 1);
+}
+
+// Seeds of one needle.  The pigeonhole argument needs n DISJOINT pieces of the needle (n = k + 1, or k + 2 for needles
+// with many errors: two intact pieces on nearby diagonals) -- they need not tile it.  A needle of key symbols only is cut
+// into n pieces of q = floor(m / n) at offsets j * q.  A needle with an N (or, in dna15, any other ambiguity code) takes
+// its pieces from its stretches of key symbols -- the n first pieces of the largest length q that yields n of them --,
+// because a piece with an N can only occur where the text has an N too, and the filter never looks there: an intact
+// piece WITHOUT one is found like any other seed.  false: the needle has no such layout with q >= q_floor.
+static bool layout_seeds(const spm_patterns *ps, uint32_t p, uint32_t q_floor, uint32_t &n_out, uint32_t &q_out,
+                         std::vector<uint16_t> &off)
+{
+    const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
+    const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
+    bool clean = true;
+    for (uint32_t i = 0; i < m; ++i)
+        clean = clean && key_symbol(ps->sigma, pat[i]);
+    const seed_plan sp = plan_seeds(m, k);
+    off.clear();
+    if (clean) {
+        n_out = sp.n;
+        q_out = sp.q;
+        for (uint32_t j = 0; j < sp.n; ++j)
+            off.push_back((uint16_t)(j * sp.q));
+        return sp.q >= q_floor;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> runs; // (begin, length) of the stretches of key symbols
+    for (uint32_t i = 0; i < m;) {
+        if (!key_symbol(ps->sigma, pat[i])) {
+            ++i;
+            continue;
+        }
+        uint32_t j = i;
+        while (j < m && key_symbol(ps->sigma, pat[j]))
+            ++j;
+        runs.emplace_back(i, j - i);
+        i = j;
+    }
+    for (uint32_t n : {sp.n, k + 1}) { // (a needle that cannot afford the surplus seed keeps k + 1)
+        for (uint32_t q = m / n; q >= q_floor && q > 0; --q) {
+            uint64_t have = 0;
+            for (const auto &r : runs)
+                have += r.second / q;
+            if (have < n)
+                continue;
+            for (const auto &r : runs)
+                for (uint32_t j = 0; j + q <= r.second && off.size() < n; j += q)
+                    off.push_back((uint16_t)(r.first + j));
+            n_out = n;
+            q_out = q;
+            return true;
+        }
+        if (sp.n == k + 1)
+            break;
+    }
+    return false;
+}
+
 // Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
 // needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
 // hits per diagonal band and skip bands with a single one (filter.hpp, candidate merging).
@@ -110,30 +180,42 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
     ps->fidx.clear();
-    if ((ps->sigma != 4 && ps->sigma != 5) || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 || ps->n >= (1u << 21))
+    if ((ps->sigma != 4 && ps->sigma != 5 && ps->sigma != 15) || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 ||
+        ps->n >= (1u << 21))
         return SPM_OK;
-    if (ps->sigma == 5) // dna5: the 2-bit keys cannot hold an N (rank 3); needles with an N go to the brute engine
-        for (uint8_t c : ps->ranks)
-            if (c == 3)
-                return SPM_OK;
     uint32_t qmin = 0xFFFFFFFFu;
     uint64_t n_seeds = 0;
+    ps->seed_q.assign(ps->n, 0);
+    ps->seed_n.assign(ps->n, 0);
+    ps->seed_first.assign(ps->n + 1, 0);
+    ps->seed_off.clear();
+    std::vector<uint16_t> off;
     for (uint32_t p = 0; p < ps->n; ++p) {
-        const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
+        const uint32_t m = (uint32_t)ps->m[p];
         if (m == 0 || m > 2047)
             return SPM_OK;
-        const seed_plan sp = plan_seeds(m, k);
-        qmin = std::min(qmin, sp.q);
-        n_seeds += sp.n;
+        uint32_t n = 0, q = 0;
+        if (!layout_seeds(ps, p, kKeyMin, n, q, off))
+            return SPM_OK; // (one needle without a layout keeps the whole set on the brute-force engine)
+        ps->seed_q[p] = (uint16_t)q;
+        ps->seed_n[p] = (uint16_t)n;
+        ps->seed_first[p] = (uint32_t)ps->seed_off.size();
+        ps->seed_off.insert(ps->seed_off.end(), off.begin(), off.end());
+        qmin = std::min(qmin, q);
+        n_seeds += n;
     }
+    ps->seed_first[ps->n] = (uint32_t)ps->seed_off.size();
     if (qmin < kKeyMin)
         return SPM_OK;
     // key length H and stride S: a window of H symbols at every S-th text position needs S <= q - H + 1.
     // Seeds of >= 17 symbols use full 32-bit keys; shorter seeds give up one or two symbols of key for stride 2
     // (half the windows), which costs far less than the extra spurious key matches it lets through.
+    // Seeds of <= 12 symbols: the whole seed is the key (stride 1) -- every symbol of key divides the chance matches by 4.
     uint32_t H = kKeyMax;
     if (qmin < kKeyMax + 1)
-        H = qmin == kKeyMin ? kKeyMin : qmin - 1;
+        H = qmin <= 12 ? qmin : qmin - 1;
+    if ((double)n_seeds / std::pow(4.0, (double)H) > kMaxSurvivorShare)
+        return SPM_OK; // too many keys for their length: most text windows would match one by chance
     const int force_h = env_int("SPM_HIP_FILTER_KEYLEN", 0);
     if (force_h >= (int)kKeyMin && force_h <= (int)std::min(qmin, kKeyMax))
         H = (uint32_t)force_h;
@@ -174,7 +256,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
             uint64_t keys = 0;
             uint32_t p1 = p0;
             while (p1 < ps->n) {
-                const uint64_t add = (uint64_t)plan_seeds((uint32_t)ps->m[p1], ps->is_myers() ? (uint32_t)ps->k[p1] : 0).n * S;
+                const uint64_t add = (uint64_t)ps->seed_n[p1] * S;
                 if (keys + add > cap && p1 > p0)
                     break;
                 keys += add;
@@ -229,14 +311,12 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
         uint32_t key, val, sig, meta;
     };
     std::vector<kv> keys;
-    auto code = [&](uint8_t c) -> uint32_t { return (ps->sigma == 5 && c == 4) ? 3u : (c & 3u); };
+    auto code = [&](uint8_t c) -> uint32_t { return key_code(ps->sigma, c); };
     for (uint32_t p = p_begin; p < p_end; ++p) {
-        const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
-        const seed_plan sp = plan_seeds(m, k);
-        const uint32_t q = sp.q;
+        const uint32_t q = ps->seed_q[p];
         const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-        for (uint32_t j = 0; j < sp.n; ++j) {
-            const uint32_t o = j * q;
+        for (uint32_t j = 0; j < ps->seed_n[p]; ++j) {
+            const uint32_t o = ps->seed_off[ps->seed_first[p] + j];
             for (uint32_t r = 0; r < S; ++r) {
                 // window seed[r, r+H) -- inside the seed because S <= q - H + 1
                 uint32_t key = 0;
@@ -372,7 +452,7 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
             F.hash_variant = 1; // key set too dense for the fingerprint table: Bloom cascade
         }
     }
-    if (ps->sigma == 5 && F.hash_variant != 2)
+    if (ps->sigma != 4 && F.hash_variant != 2)
         return SPM_OK; // the dna5 kernel is built for the fingerprint table only
     if (F.hash_variant != 2) {
         uint64_t want_bits = F.n_keys * 32;
@@ -503,7 +583,7 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         }
     SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq, peq.size() * sizeof(uint32_t)));
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq, peq.data(), peq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!myers && sigma <= 5) {
+    if (!myers && (sigma <= 5 || sigma == 15)) {
         // the filter engine verifies exact matchers with the Myers recurrence at k = 0: match masks, not Shift-Or's
         std::vector<uint32_t> vq(peq.size(), 0);
         for (uint32_t p = 0; p < n_patterns; ++p) {
@@ -544,7 +624,7 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
     SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 
     // ---- filter engine tables (verification reads the brute table) ----
-    if ((sigma == 4 || sigma == 5) && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
+    if ((sigma == 4 || sigma == 5 || sigma == 15) && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
         int rc = build_filter_index(ctx, ps.get());
         if (rc != SPM_OK)
             return rc;
@@ -562,11 +642,14 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
                 SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
             SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t),
                                          hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_seed_q, ps->seed_q.size() * sizeof(uint16_t)));
+            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_seed_q, ps->seed_q.data(), ps->seed_q.size() * sizeof(uint16_t),
+                                         hipMemcpyHostToDevice));
         }
         if (!ps->fidx.empty() && ps->max_k >= kMergeMinK && ps->max_k <= 1000) {
             std::vector<uint8_t> surplus(ps->m.size(), 1);
             for (uint32_t p = 0; p < ps->n; ++p)
-                surplus[p] = (uint8_t)(plan_seeds((uint32_t)ps->m[p], (uint32_t)ps->k[p]).n - (uint32_t)ps->k[p]);
+                surplus[p] = (uint8_t)(ps->seed_n[p] - (uint32_t)ps->k[p]);
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_surplus, surplus.size()));
             SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_surplus, surplus.data(), surplus.size(), hipMemcpyHostToDevice));
         }
@@ -589,6 +672,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_ranks);
     hipFree(p->d_offsets);
     hipFree(p->d_pass_tab);
+    hipFree(p->d_seed_q);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
@@ -1349,7 +1433,8 @@ int run_filter(const scan_args &A)
     // Other sets: 64 diagonals, no overlap -- every band with a seed hit is verified.
     uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
     const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-band kernel
-    const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min;
+    // (the wave-per-band kernel keeps the match masks of <= 5 symbols in registers: dna15 sets use the lane-per-band one)
+    const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min && ps->sigma <= 5;
     const bool overlap = ps->d_surplus != nullptr;
     uint32_t Bw;
     if (overlap) {
@@ -1479,6 +1564,11 @@ int run_filter(const scan_args &A)
                 LAUNCH_FILTER4(S, UU, true, 2, 5, km);                                                                 \
             else                                                                                                       \
                 LAUNCH_FILTER4(S, UU, true, 2, 5, false);                                                              \
+        } else if (ps->sigma == 15) {                                                                                  \
+            if (short_keys)                                                                                            \
+                LAUNCH_FILTER4(S, UU, true, 2, 15, km);                                                                \
+            else                                                                                                       \
+                LAUNCH_FILTER4(S, UU, true, 2, 15, false);                                                             \
         } else {                                                                                                       \
             if (short_keys)                                                                                            \
                 LAUNCH_FILTER4(S, UU, NTT, HV, 4, km);                                                                 \
@@ -1597,6 +1687,7 @@ int run_filter(const scan_args &A)
     R.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
     R.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
     R.needle_offsets = ps->d_offsets;
+    R.seed_q = ps->d_seed_q;
     R.flank_check = (ps->sigma == 4 && !overlap && R.needle_ranks && env_int("SPM_HIP_FLANK_CHECK", 1)) ? 1u : 0u;
     R.pieces_check = env_int("SPM_HIP_PIECES_CHECK", 1) ? R.flank_check : 0u;
     R.m = ps->d_m;
@@ -2262,19 +2353,25 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
         stats[2] = keys_total;
         uint64_t expect = 0;
         for (uint32_t p = 0; p < n_patterns; ++p)
-            expect += (uint64_t)plan_seeds((uint32_t)ps.m[p], ps.is_myers() ? (uint32_t)ps.k[p] : 0).n * S;
+            expect += (uint64_t)ps.seed_n[p] * S;
         if (expect != keys_total)
             return SPM_E_INVALID;
     }
     size_t fi = 0;
     uint64_t in_pass = 0;
     for (uint32_t p = 0; p < n_patterns; ++p) {
-        const uint32_t m = (uint32_t)ps.m[p], kk = (uint32_t)ps.k[p];
-        const seed_plan sp = plan_seeds(m, ps.is_myers() ? kk : 0);
-        const uint32_t q = sp.q;
-        if (S > q - (ps.filter_key_len - 1))
-            return SPM_E_INVALID; // sampling would miss occurrences
-        const uint64_t mine = (uint64_t)sp.n * S;
+        const uint32_t q = ps.seed_q[p], sn = ps.seed_n[p];
+        if (S > q - (ps.filter_key_len - 1) || sn < (ps.is_myers() ? (uint32_t)ps.k[p] : 0u) + 1)
+            return SPM_E_INVALID; // sampling would miss occurrences / too few seeds for the pigeonhole argument
+        for (uint32_t j = 0; j < sn; ++j) { // seeds: inside the needle, disjoint, key symbols only
+            const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
+            if (o + q > (uint32_t)ps.m[p] || (j && o < ps.seed_off[ps.seed_first[p] + j - 1] + q))
+                return SPM_E_INVALID;
+            for (uint32_t i = 0; i < q; ++i)
+                if (!key_symbol(sigma, ps.ranks[ps.offsets[p] + o + i]))
+                    return SPM_E_INVALID;
+        }
+        const uint64_t mine = (uint64_t)sn * S;
         while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
             if (in_pass != ps.fidx[fi].n_keys)
                 return SPM_E_INVALID;
@@ -2286,15 +2383,14 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
         in_pass += mine;
         const filter_index &F = ps.fidx[fi];
         const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
-        for (uint32_t j = 0; j < sp.n; ++j)
+        for (uint32_t j = 0; j < sn; ++j)
             for (uint32_t r = 0; r < S; ++r) {
+                const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
                 uint32_t key = 0;
-                for (uint32_t i = 0; i < ps.filter_key_len; ++i) {
-                    const uint8_t c = pat[j * q + r + i];
-                    key |= (uint32_t)((sigma == 5 && c == 4) ? 3u : (c & 3u)) << (2 * i);
-                }
+                for (uint32_t i = 0; i < ps.filter_key_len; ++i)
+                    key |= key_code(sigma, pat[o + r + i]) << (2 * i);
                 ++checked;
-                if (!level1(F, key) || !level2(F, key, (p << 11) | (j * q + r)))
+                if (!level1(F, key) || !level2(F, key, (p << 11) | (o + r)))
                     ++missing;
             }
     }

@@ -606,7 +606,8 @@ def test_fuzz_long_needles_many_errors(spm, ctx, oracle):
 
 def test_dna5_haystack_through_the_seed_filter(spm, ctx, oracle):
     """dna5 text (ranks A0 C1 G2 N3 T4) with runs of N and isolated Ns: the seed filter drops windows containing an
-    N, verification runs on 5 Peq rows.  filter == brute == oracle.  Needles with an N are not filterable."""
+    N, verification runs on 5 Peq rows.  filter == brute == oracle.  Needles with Ns take their seeds from their N-free
+    stretches."""
     rng = np.random.default_rng(55)
     n = 1 << 20
     T = rng.choice(np.array([0, 1, 2, 4], dtype=np.uint8), n)
@@ -642,9 +643,30 @@ def test_dna5_haystack_through_the_seed_filter(spm, ctx, oracle):
         want += [(j, int(x), int(s)) for x, s in zip(r["pos"], r["score"])]
     got = [(sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub]
     assert sorted(got) == sorted(want)
-    with_n = [nd.copy() for nd in needles[:4]]
-    with_n[0][10] = 3
-    assert not ctx.patterns(spm.ALGO_MYERS, with_n, k=3, sigma=5).filterable
+    # needles WITH Ns stay on the filter: their seeds come from the N-free stretches.  An N in a needle matches an N in
+    # the text (rank equality, as in the reference), so plant copies whose Ns sit on text Ns, too
+    with_n = [nd.copy() for nd in needles[:24]]
+    for i, nd in enumerate(with_n):
+        nd[[10, 47, 80][i % 3]] = 3
+        if i % 4 == 0:
+            nd[55:58] = 3
+        p = 50_000 + 2_000 * i
+        T2 = nd.copy()
+        if i % 2:
+            T2[20] = [0, 1, 2, 4][(int(T2[20]) + 1) % 4 if T2[20] < 3 else 0]   # one substitution elsewhere
+        T[p:p + len(T2)] = T2
+    text = ctx.upload(T, sigma=5)
+    pn = ctx.patterns(spm.ALGO_MYERS, with_n, k=3, sigma=5)
+    assert pn.filterable
+    hn = spm.scan(ctx, text, pn, engine=spm.ENGINE_FILTER)
+    assert hn.stats().engine_used == spm.ENGINE_FILTER and hn.stats().fell_back == 0
+    assert np.array_equal(hn.view(), spm.scan(ctx, text, pn, engine=spm.ENGINE_BRUTE).view())
+    assert len(np.unique(hn.view()["pattern"])) == len(with_n)
+    want = []
+    for j in range(0, 24, 5):
+        r = oracle.myers(T, with_n[j], 3, sigma=5)
+        want += [(j, int(x), int(s)) for x, s in zip(r["pos"], r["score"])]
+    assert sorted(x for x in _hits_list(hn.view()) if x[0] % 5 == 0 and x[0] < 24) == sorted(want)
     # exact matcher on dna5
     pe = ctx.patterns(spm.ALGO_SHIFTOR, [nd[:40] for nd in needles[:64]], sigma=5)
     assert pe.filterable
@@ -787,3 +809,75 @@ def test_restorable_chunks_through_the_seed_filter(spm, ctx, oracle, algo, L, k)
     hb0, sb0 = spm.scan(ctx, ctx.upload(T[:cuts[1]]), ps, want_state=True, engine=spm.ENGINE_BRUTE)
     assert h0.stats().engine_used == spm.ENGINE_FILTER
     assert np.array_equal(s0, sb0) and np.array_equal(h0.view(), hb0.view())
+
+
+def test_dna15_haystack_through_the_seed_filter(spm, ctx, oracle):
+    """dna15 (seqan3 ranks A0 B1 C2 D3 G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T are the key symbols, every
+    ambiguity code -- in the text or in a needle -- is treated like dna5's N (rank equality decides a match, as in the
+    reference).  filter == brute == oracle."""
+    rng = np.random.default_rng(1515)
+    n = 1 << 20
+    T = np.array([0, 2, 4, 11], dtype=np.uint8)[rng.integers(0, 4, n)]
+    amb = np.array([1, 3, 5, 6, 7, 8, 9, 10, 12, 13, 14], dtype=np.uint8)
+    T[rng.integers(0, n, 3000)] = amb[rng.integers(0, len(amb), 3000)]   # isolated ambiguity codes
+    for at in rng.integers(0, n - 2000, 20):
+        T[at:at + int(rng.integers(1, 1500))] = 8                         # runs of N
+    needles = []
+    for i in range(80):
+        at = int(rng.integers(0, n - 400))
+        nd = T[at:at + 100].copy()
+        if i % 2 == 0:
+            nd[np.isin(nd, amb)] = 0                                      # half of the needles are ACGT only
+        if i % 3 == 1:
+            nd[60] = 2 if nd[60] != 2 else 4
+        if i % 3 == 2:
+            nd = np.delete(nd, 25)
+        needles.append(nd)
+        p = 10_000 + 5_000 * i
+        T[p:p + len(nd)] = nd
+    text = ctx.upload(T, sigma=15)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3, sigma=15)
+    assert ps.filterable
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
+    assert hf.stats().engine_used == spm.ENGINE_FILTER and hf.stats().fell_back == 0
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE)
+    assert np.array_equal(hf.view(), hb.view())
+    assert len(np.unique(hf.view()["pattern"])) == len(needles)
+    want = []
+    for j in range(0, 80, 9):
+        r = oracle.myers(T, needles[j], 3, sigma=15)
+        want += [(j, int(x), int(s)) for x, s in zip(r["pos"], r["score"])]
+    assert sorted(x for x in _hits_list(hf.view()) if x[0] % 9 == 0) == sorted(want)
+    pe = ctx.patterns(spm.ALGO_SHIFTOR, [nd[:40] for nd in needles[::2]], sigma=15)
+    assert pe.filterable
+    assert np.array_equal(spm.scan(ctx, text, pe, engine=spm.ENGINE_FILTER).view(),
+                          spm.scan(ctx, text, pe, engine=spm.ENGINE_BRUTE).view())
+
+
+@pytest.mark.parametrize("m,k", [(32, 2), (44, 3), (27, 2), (30, 1), (20, 1)])
+def test_short_seeds_through_the_seed_filter(spm, ctx, oracle, m, k):
+    """Seeds of 9 .. 15 symbols (|P| = 32, k = 2 and the like): the whole seed is the key, thousands of chance matches
+    per megabase are resolved after the streaming pass.  filter == brute == oracle."""
+    rng = np.random.default_rng(100 * m + k)
+    n = 1 << 21
+    T = oracle.text(0x5EED0001, 0, n)
+    needles = []
+    for i in range(200):
+        at = int(rng.integers(0, n - 2 * m))
+        nd = T[at:at + m].copy()
+        for e in range(i % (k + 1)):
+            nd[(7 * e + 3 + i) % m] ^= 1 + (i & 1)
+        needles.append(nd)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    assert ps.filterable
+    text = ctx.upload(T)
+    hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 22)
+    st = hf.stats()
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0 and st.fallback_spans == 0
+    hb = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 22)
+    assert np.array_equal(hf.view(), hb.view())
+    assert len(np.unique(hf.view()["pattern"])) == len(needles)
+    sub = list(range(0, 200, 23))
+    want = _oracle_multi(oracle, "myers", T, [needles[i] for i in sub], [k] * len(sub))
+    got = sorted((sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub)
+    assert got == want

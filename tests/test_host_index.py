@@ -68,7 +68,14 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 48, dtype=np.uint8)], 3)      # q = 12
     assert rc == 0 and st["missing"] == 0 and (st["key_len"], st["stride"]) == (12, 1)
     # seeds shorter than the shortest key: the filter does not apply
-    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 44, dtype=np.uint8)], 3)
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 32, dtype=np.uint8)], 3)
+    assert rc == 0 and st["passes"] == 0
+    # seeds of 9 .. 11 symbols: the whole seed is the key, stride 1
+    for m, k, q in ((44, 3, 11), (32, 2, 10), (27, 2, 9)):
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, m, dtype=np.uint8) for _ in range(100)], k)
+        assert rc == 0 and st["passes"] == 1 and st["missing"] == 0 and st["stride"] == 1 and st["key_len"] == q, (m, k, st)
+    # ... unless there are so many of them that most text windows would match one by chance
+    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 27, dtype=np.uint8) for _ in range(20000)], 2)
     assert rc == 0 and st["passes"] == 0
 
 
@@ -77,10 +84,23 @@ def test_dna5_and_bloom_fallback(spm):
     needles = [rng.choice(np.array([0, 1, 2, 4], dtype=np.uint8), 100) for _ in range(256)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, needles, 3, sigma=5)
     assert rc == 0 and st["passes"] == 1 and st["missing"] == 0
+    # needles with N: their seeds are taken from the N-free stretches (k + 1 disjoint pieces are all the pigeonhole
+    # argument needs), so the set stays filterable; the self-test checks that no indexed seed holds an N
     with_n = [x.copy() for x in needles]
     with_n[7][50] = 3
+    with_n[8][[0, 31, 62, 99]] = 3
+    with_n[9][10:20] = 3
     rc, st = _selftest(spm, spm.ALGO_MYERS, with_n, 3, sigma=5)
-    assert rc == 0 and st["passes"] == 0                             # an N in a needle: brute engine
+    assert rc == 0 and st["passes"] == 1 and st["missing"] == 0
+    with_n[10][::8] = 3                                              # no stretch of 12 key symbols left: brute engine
+    rc, st = _selftest(spm, spm.ALGO_MYERS, with_n, 3, sigma=5)
+    assert rc == 0 and st["passes"] == 0
+    # dna15 (A0 C2 G4 T11 are the key symbols): the same, with every other code standing in for N
+    d15 = [np.array([0, 2, 4, 11], dtype=np.uint8)[rng.integers(0, 4, 100)] for _ in range(64)]
+    d15[3][40] = 8
+    d15[4][5] = 14
+    rc, st = _selftest(spm, spm.ALGO_MYERS, d15, 3, sigma=15)
+    assert rc == 0 and st["passes"] == 1 and st["missing"] == 0
     os.environ["SPM_HIP_FILTER_HASH"] = "1"                          # force the Bloom cascade
     try:
         rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 100, dtype=np.uint8) for _ in range(1024)], 3)
