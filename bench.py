@@ -276,7 +276,11 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
     the host cores, on a bounded sample of the same workload.  A reported baseline, not the target."""
     from oracle import oracle as O
     native = O.use_native_build()  # -O3 -march=native on this host (oracle/Makefile, target `native`)
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:  # the CPUs this process may actually run on (a GPU box hands a job a share of its cores)
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     o_algo = O.MYERS if algo == "myers" else O.SHIFTOR
     pats = [O.pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(64)]
     # calibrate on one core

@@ -265,6 +265,26 @@ int spm_hip_jst_synth_variants(uint64_t seed_text, uint64_t seed_var, uint64_t r
                                uint32_t n_haplotypes, spm_jst_allele *alleles, uint64_t *n_alleles, uint8_t *alt_pool,
                                uint64_t *alt_pool_len, uint64_t *coverage);
 
+/* ---- multi-GPU exchange: the gatherv of hit records to one rank over RCCL (xGMI), SURVEY.md 8(e) -------------------
+ * One process per GPU; the path shards by text position (spm_scan_opts.left_context / pos_offset) and needs no
+ * data-path collective.  The single exchange step is this gatherv (RCCL has none of its own: one ncclAllGather of the
+ * per-rank counts, then grouped ncclSend / ncclRecv).  librccl.so is opened when the first communicator is made.
+ *   rank 0:      spm_hip_comm_unique_id(id)  -> hand the 128 bytes to the other ranks (MPI, a file, a socket ...)
+ *   every rank:  spm_hip_comm_init(ctx, id, rank, world, &comm)
+ *   per scan:    spm_hip_gatherv_hits(comm, hits, 0, &records, &n, counts)
+ * Records arrive in rank order (= ascending shard order); on the root *device_records points at n_total records in HBM
+ * (owned by the communicator, valid until its next gatherv), elsewhere it is NULL.  counts may be NULL. */
+typedef struct spm_comm spm_comm;
+int spm_hip_comm_unique_id(void *id128);
+int spm_hip_comm_init(spm_ctx *ctx, const void *unique_id128, int rank, int world, spm_comm **out);
+void spm_hip_comm_destroy(spm_comm *comm);
+int spm_hip_gatherv_hits(spm_comm *comm, spm_hits *local, int root, const void **device_records, uint64_t *n_total,
+                         uint64_t *counts);
+int spm_hip_gatherv_jst_hits(spm_comm *comm, spm_jst_hits *local, int root, const void **device_records,
+                             uint64_t *n_total, uint64_t *counts);
+/* host arithmetic of the gatherv: byte offset of every rank's records in the root's buffer, offsets[world] = total */
+int spm_hip_gatherv_plan(const uint64_t *counts, uint32_t world, uint32_t record_bytes, uint64_t *offsets);
+
 /* ---- synthetic needles of the benchmark configs (host side) -------------------------- */
 uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,
                                uint32_t kmax, uint8_t *out);

@@ -159,6 +159,13 @@ def lib():
         "spm_hip_jst_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "spm_hip_jst_hits_copy_device": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         "spm_hip_jst_hits_destroy": (None, [vp]),
+        "spm_hip_comm_unique_id": (C.c_int, [vp]),
+        "spm_hip_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "spm_hip_comm_destroy": (None, [vp]),
+        "spm_hip_gatherv_hits": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "spm_hip_gatherv_jst_hits": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_uint64)]),
+        "spm_hip_gatherv_plan": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "spm_hip_jst_synth_variants": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                                  C.POINTER(JstAllele), C.POINTER(C.c_uint64), u8p,
                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -183,4 +190,6 @@ EXPORTS = [
     "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",
     "spm_hip_jst_hits_copy_device", "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",
+    "spm_hip_comm_unique_id", "spm_hip_comm_init", "spm_hip_comm_destroy", "spm_hip_gatherv_hits",
+    "spm_hip_gatherv_jst_hits", "spm_hip_gatherv_plan",
 ]

@@ -2413,3 +2413,4 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
 extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.1 (gfx950)"; }
 
 #include "jst.hpp"
+#include "comm.hpp"

@@ -57,3 +57,19 @@ def test_product_never_imports_oracle():
                     if re.search(r"(import\s+oracle|from\s+oracle|spm_oracle\.h|libspm_oracle)", src):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_gatherv_plan_offsets(spm):
+    """Host arithmetic of the native gatherv (spm_hip_gatherv_plan): rank r's records land at offsets[r] bytes."""
+    import numpy as np
+    L = spm.capi.lib()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    counts = np.array([3, 0, 7, 1], dtype=np.uint64)
+    offs = np.zeros(5, dtype=np.uint64)
+    assert L.spm_hip_gatherv_plan(counts.ctypes.data_as(u64p), 4, 16, offs.ctypes.data_as(u64p)) == 0
+    assert offs.tolist() == [0, 48, 48, 160, 176]
+    assert L.spm_hip_gatherv_plan(counts.ctypes.data_as(u64p), 4, 24, offs.ctypes.data_as(u64p)) == 0
+    assert offs.tolist() == [0, 72, 72, 240, 264]
+    huge = np.array([1 << 62, 1 << 62], dtype=np.uint64)
+    assert L.spm_hip_gatherv_plan(huge.ctypes.data_as(u64p), 2, 16, offs.ctypes.data_as(u64p)) == -5   # SPM_E_OVERFLOW
+    assert L.spm_hip_gatherv_plan(None, 2, 16, offs.ctypes.data_as(u64p)) == -1

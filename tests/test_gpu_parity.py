@@ -881,3 +881,35 @@ def test_short_seeds_through_the_seed_filter(spm, ctx, oracle, m, k):
     want = _oracle_multi(oracle, "myers", T, [needles[i] for i in sub], [k] * len(sub))
     got = sorted((sub.index(p), pos, s) for p, pos, s in _hits_list(hf.view()) if p in sub)
     assert got == want
+
+
+def test_native_rccl_gatherv_world_of_one(spm, ctx, oracle):
+    """The C-ABI exchange entry (spm_hip_comm_* / spm_hip_gatherv_hits): librccl.so is opened on demand, a communicator
+    of one rank is made, and the gatherv hands back this rank's records unchanged -- the count all-gather and the root's
+    own copy run; the send/recv legs need a multi-GPU box (the offsets they use are checked on the CPU)."""
+    import ctypes as C
+    L = spm.capi.lib()
+    uid = (C.c_char * 128)()
+    assert L.spm_hip_comm_unique_id(uid) == 0
+    comm = C.c_void_p()
+    rc = L.spm_hip_comm_init(ctx._h, uid, 0, 1, C.byref(comm))
+    assert rc == 0, L.spm_hip_last_error(ctx._h)
+    try:
+        n = 1 << 20
+        text = ctx.generate(0x5EED0001, 0, n)
+        needles = [spm.synth_pattern(0x5EED0001, 0x5EED0002, n, p, 100, 3)[0] for p in range(64)]
+        ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+        h = spm.scan(ctx, text, ps)
+        want = h.view()
+        rec, tot = C.c_void_p(), C.c_uint64()
+        counts = (C.c_uint64 * 1)()
+        assert L.spm_hip_gatherv_hits(comm, h._h, 0, C.byref(rec), C.byref(tot), counts) == 0
+        assert tot.value == len(want) == counts[0] and len(want) >= 64
+        got = np.empty(tot.value, dtype=spm.HIT_DTYPE)
+        buf = (C.c_char * (16 * tot.value)).from_buffer(got)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(buf, rec, 16 * tot.value, 2) == 0          # hipMemcpyDeviceToHost
+        assert np.array_equal(np.sort(got, order=["pattern", "pos"]), want)
+        assert L.spm_hip_gatherv_hits(comm, h._h, 3, C.byref(rec), C.byref(tot), counts) == -1   # no such root
+    finally:
+        L.spm_hip_comm_destroy(comm)
