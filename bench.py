@@ -53,6 +53,25 @@ VALU_PEAK_LANE_OPS = 6.5e13   # measured: v_add_u32 / v_bitop3_b32 chains, 8 wav
 VALU_NOMINAL_LANE_OPS = 256 * 128 * 2.4e9
 
 
+def live_stream_probe():
+    """Best pure streaming read of a 16 GiB buffer on THIS GPU, measured now by tools/hbm_read_probe (a standalone HIP
+    program built by build(); run as a child process once every buffer of the bench is released).  None if absent."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "hbm_read_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+        best = 0.0
+        for line in out.splitlines():
+            f = line.split()
+            if len(f) >= 8 and f[0] in ("span", "inter"):
+                best = max(best, float(f[-1]))
+        return best or None
+    except Exception:
+        return None
+
+
 def valu_roofline(workload, n_pat, lane_steps_per_s):
     """SURVEY 8(d)(ii) for the brute-force engine: lane-ops/s against the measured integer-VALU issue peak.
 
@@ -388,9 +407,23 @@ def main():
             result = run_scan(args, *env, workload=args.workload)
         # One driver-timed line that covers every BASELINE config: the default run (C3, one GPU) also executes C2, C4's
         # per-GPU shard, C5 and the repeat-rich C3 text, each >= 3 timed repetitions (test/benchmark/CMakeLists.txt:12-14)
-        if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs and args.engine == "auto"
-                and args.text_gib is None and args.needles is None):
+        default_run = (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs
+                       and args.engine == "auto" and args.text_gib is None and args.needles is None)
+        if default_run:
             result["other_configs"] = other_configs(args, env)
+    if default_run:
+        # what this GPU streams at best (measured now, not a tracked constant); `frac` stays against the 8 TB/s spec peak
+        ctx.close()
+        torch.cuda.empty_cache()
+        probe = live_stream_probe()
+        rf = result["roofline"]
+        if probe:
+            rf["stream_read_probe"] = probe
+            rf["frac_of_stream_read_probe"] = rf["achieved"] / probe
+            rf["stream_read_probe_source"] = "measured in this run (tools/hbm_read_probe, 16 GiB, best access shape)"
+        else:
+            rf["stream_read_probe_source"] = "profiles/r01/hbm_read_probe_16GiB.log (tools/hbm_read_probe not built)"
+        rf["traffic_source"] = "rocprofv3 PMC passes of the same workload (profiles/pmc_traffic.json); not measured in this run"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             algo, L, kmax, n_pat, gib, _ = WORKLOADS[args.workload]
@@ -474,14 +507,20 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         cap = max_hits
     hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
     count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+    # few records (C2, C3: <= 128 KB per rank): one fused all-gather of fixed-size buffers, no count exchange;
+    # many (C4: ~51 000 hits per rank, c3r: millions): the count-then-send gatherv moves what there is, not the capacity
+    fused = cap <= (1 << 13)
 
     def step():
         h = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
                    pos_offset=lo - ovl, max_hits=max_hits)
         n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
-        count_host[0] = n
-        hit_buf[0].copy_(count_host, non_blocking=True)  # count
-        gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
+        if fused:
+            count_host[0] = n
+            hit_buf[0].copy_(count_host, non_blocking=True)  # count
+            gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
+        else:
+            gathered = sdist.gatherv_hits(hit_buf[1:1 + min(n, cap)])
         return h, gathered
 
     for _ in range(args.warmup):
@@ -515,7 +554,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     st, gathered = last
     if rank != 0:
         return None
-    recs = sdist.split_fused(gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
+    recs = (sdist.split_fused(gathered) if fused else gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
     hits = np.frombuffer(recs.tobytes(), dtype=S.HIT_DTYPE)
     found = np.unique(hits["pattern"])
     ms_per_step = dt / args.steps * 1e3
@@ -552,8 +591,10 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         "config": {"workload": f"{workload}: {desc}", "needles": n_pat, "needle_len": L, "k": kmax,
                    "text_bytes_per_gpu": hi - lo, "engine": engine_used,
                    "sharding": (f"text position, {world} shard(s), {window - 1}-symbol left context, hit records "
-                                "exchanged with one fused all-gather per step (fixed-size [count | records] buffers; "
-                                "the count-then-send gatherv, libspm_amd.dist.gatherv_hits, is what C5 uses)")
+                                + ("exchanged with one fused all-gather per step (fixed-size [count | records] buffers of "
+                                   f"{(cap + 1) * 16} bytes per rank)" if fused else
+                                   "gathered to rank 0 per step (count all-gather + grouped send/recv: "
+                                   "libspm_amd.dist.gatherv_hits)"))
                    if world > 1 else "single GPU"},
         "roofline": {
             "bound": "hbm",
