@@ -46,8 +46,7 @@ struct spm_ctx
     std::vector<hits_block> pool;
     std::vector<std::pair<void *, uint64_t>> jst_pool; // record buffers of journaled-sequence searches (pointer, capacity)
     // band table of the filter engine: empty between scans (see run_filter)
-    unsigned long long *d_band_keys = nullptr;
-    unsigned long long *d_band_val = nullptr;
+    ulonglong2 *d_band_tab = nullptr; // {key, value} per slot (filter.hpp: band_value)
     uint64_t band_slots = 0;
     bool band_dirty = false;
     unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs

@@ -72,9 +72,9 @@ struct survivor
 };
 constexpr uint32_t kSurvInvalid = 0xFFFFFFFFu;
 
-struct pass_entry // exact key table of one pass, in L2
+struct pass_entry // key directory of one pass, in L2
 {
-    const uint4 *ht; // {key, val = pattern << 11 | offset, seed signature, range code}; val == kHtEmpty: empty slot
+    const uint4 *ht; // {key, first entry, entries, -}, open addressing; an empty slot has .z == 0
     uint32_t ht_mask;
     uint32_t pad;
 };
@@ -850,8 +850,7 @@ struct verify_params
     uint32_t band_counter;              // 3: the list resolve_kernel wrote; 10: the list band_select_kernel kept
     uint32_t preselected;               // 1: the list holds only bands with enough seed hits, their table slots reset
     uint64_t band_cap;
-    unsigned long long *band_keys;      // band table (reset slot by slot as the bands are consumed)
-    unsigned long long *band_val;       // overlapping bands: seed hits counted; else: bit mask of the diagonals hit
+    ulonglong2 *band_tab;               // band table (slots are given back as the bands are consumed), see band_value()
     const uint8_t *surplus; // per needle: seed hits a band needs (seeds - k); nullptr = 1 for every needle
     uint32_t Bw;            // diagonals per band
     uint32_t overlap;       // 1: bands extend k + 1 diagonals into the next one (sets with surplus seeds)
@@ -899,10 +898,11 @@ struct resolve_params
     unsigned long long *counters; // [1] survivor slots drawn (this pass), [3] band slots drawn, [5] candidates (stat),
                                   // [8] survivors over all passes, [9] largest survivor demand of a pass, [2] overflow
     uint64_t surv_cap;
-    const pass_entry *passes; // exact key tables, one per pass
+    const pass_entry *passes; // key directories, one per pass
+    const uint4 *entries;     // {val = needle << 11 | offset, seed signature, range code, key}: a key's entries side by side
     uint32_t key_len;
     uint32_t flank_check;     // 1: dna4 set without surplus seeds: seed signatures are checked against the packed text
-    uint32_t pieces_check;    // 1: ... and the piece count (see pieces_plausible)
+    uint32_t pieces_check;    // 1: ... and the piece count (see pieces_visit)
     const uint8_t *text;
     uint64_t text_alloc;            // readable bytes from text
     const uint8_t *needle_ranks;    // the needles' symbols back to back, padded (nullptr: no whole-seed check)
@@ -914,12 +914,27 @@ struct resolve_params
     uint64_t n_segments;
     uint32_t Bw, overlap, max_m;
     uint32_t band_bits;             // key = pattern << 43 | segment << band_bits | band
-    unsigned long long *band_keys;
-    unsigned long long *band_val; // overlapping bands: seed-hit count; else: bit d set = a seed hit on diagonal d of the band
+    ulonglong2 *band_tab;           // {key, value} per slot, see band_value()
     uint32_t table_mask;
     band_rec *bands;
     uint64_t band_cap;
+    const uint32_t *needle_pk;      // dna4 sets: the needles 2 bits per symbol, 16 symbols per word (pack16's bit order)
+    const uint32_t *pk_offsets;     // first word of every needle in needle_pk
 };
+
+// Band table slot: .x = key (kBandEmpty = all ones: free), .y = value kept so that a free slot is ALL ONES (one memset
+// clears the table, one 16-byte store gives a slot back): the complement of the mask of diagonals hit, or the number of
+// seed hits minus one (mod 2^64).  Key and value share a slot because a table of 10^6..10^7 slots lives in HBM and a
+// random access there costs a DRAM row, not bytes: the insert's compare-and-swap and the update of the value, and later
+// the consumer's read and reset, touch one line each instead of two.
+__device__ __forceinline__ unsigned long long band_value(unsigned long long stored, bool counting)
+{
+    return counting ? (unsigned long long)(uint32_t)(stored + 1ull) : ~stored;
+}
+__device__ __forceinline__ void band_release(ulonglong2 *tab, uint32_t slot)
+{
+    tab[slot] = make_ulonglong2(kBandEmpty, ~0ull);
+}
 
 // 16 bytes from an arbitrary address with ONE load: gfx950 under amdhsa runs with unaligned access enabled, so an
 // align-1 copy of 16 bytes is a single global_load_dwordx4.  (Byte loads would cost the memory pipe 16 instructions, each
@@ -991,37 +1006,63 @@ __device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t,
 // unit (their unique part fails after two or three blocks); each would have cost a band and a verification of ~170
 // columns.  Needles that ARE a repeat pass, as they must: they occur there.  A pair whose needle would stick out of the
 // haystack is not checked.
-__device__ __forceinline__ bool pieces_plausible(const resolve_params &P, uint64_t t, uint32_t val, int64_t hay_b, int64_t hay_e)
+//
+// The count runs two rounds (32 needle symbols, four pieces) per visit, starting at the end of the needle that is far
+// from the seed -- the seed sits in the part the needle shares with the text, what differs is at the other end -- and a
+// pair that is neither rejected nor through goes back into the wave's queue: on a repeat-rich text 85 % of the pairs are
+// rejected in the first visit, and the other lanes of the wave do not wait for the 15 % that need all the rounds.
+// Progress lives in the pair's `rng` word: rounds done (bits 20..26), pieces missing (27..29).
+constexpr uint32_t kPieceRoundsShift = 20, kPieceMissingShift = 27;
+
+__device__ __forceinline__ bool pieces_apply(const resolve_params &P, uint64_t t, uint32_t val, uint32_t m, uint32_t k, int64_t hay_b,
+                                             int64_t hay_e)
 {
-    if (!P.pieces_check)
-        return true;
+    if (!P.pieces_check || k == 0 || k > 7 || m < 32)
+        return false;
+    const int64_t d = (int64_t)t - (int64_t)(val & 0x7FF);
+    return d - (int64_t)k >= hay_b && d + (int64_t)(m + k) <= hay_e;
+}
+
+// one visit; returns 0: rejected, 1: more rounds to go (rng updated), 2: through
+__device__ __forceinline__ uint32_t pieces_visit(const resolve_params &P, uint64_t t, uint32_t val, uint32_t &rng, uint32_t m, uint32_t k)
+{
     const uint32_t pat = val >> 11, x = val & 0x7FF;
-    const uint32_t m = (uint32_t)P.m[pat], k = (uint32_t)P.k[pat];
-    if (k == 0 || k > 7 || m < 32)
-        return true;
-    const int64_t d = (int64_t)t - (int64_t)x;
-    if (d - (int64_t)k < hay_b || d + (int64_t)(m + k) > hay_e)
-        return true;
-    const uint8_t *nd = P.needle_ranks + P.needle_offsets[pat]; // (padded: whole 16-byte loads)
-    uint32_t missing = 0;
-    for (uint32_t y = 0; y + 16 <= m; y += 16) { // two pieces per 16 needle symbols
-        const uint32_t two = pack16(load_bytes16(nd + y));
-        // text [d + y - k, d + y + 16 + k): 16 + 2k <= 30 symbols
-        const uint64_t w0 = (uint64_t)(d + (int64_t)y - (int64_t)k);
-        const uint64_t win = (uint64_t)pack16(load_bytes16_guarded(P.text, w0, P.text_alloc)) |
-                             ((uint64_t)pack16(load_bytes16_guarded(P.text, w0 + 16, P.text_alloc)) << 32);
+    const uint32_t n_rounds = m >> 4; // two pieces per 16 needle symbols
+    uint32_t done = (rng >> kPieceRoundsShift) & 0x7F, missing = (rng >> kPieceMissingShift) & 7;
+    const bool ascending = 2 * x >= m; // seed in the right half: start at the left end
+    const uint32_t todo = n_rounds - done < 2 ? n_rounds - done : 2;
+    // rounds `done`, `done + 1` in visiting order are the needle words r_lo, r_lo + 1 (if todo == 2)
+    const uint32_t r_lo = ascending ? done : n_rounds - done - todo;
+    const uint32_t *pk = P.needle_pk + P.pk_offsets[pat] + r_lo;
+    const uint32_t nw0 = pk[0], nw1 = todo == 2 ? pk[1] : 0;
+    // text [d + 16 r_lo - k, ... + 48): 16 + 2k <= 30 symbols per round, the two rounds share the middle load
+    const uint64_t w0 = (uint64_t)((int64_t)t - (int64_t)x + (int64_t)(16 * r_lo) - (int64_t)k);
+    const uint32_t c0 = pack16(load_bytes16_guarded(P.text, w0, P.text_alloc));
+    const uint32_t c1 = pack16(load_bytes16_guarded(P.text, w0 + 16, P.text_alloc));
+    const uint32_t c2 = todo == 2 ? pack16(load_bytes16_guarded(P.text, w0 + 32, P.text_alloc)) : 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            const uint32_t piece = (two >> (16 * j)) & 0xFFFFu;
-            bool found = false;
-            for (uint32_t sh = 0; sh <= 2 * k; ++sh) // displacement sh - k
-                found = found || (((uint32_t)(win >> (2 * (8 * j + sh))) & 0xFFFFu) == piece);
-            missing += found ? 0u : 1u;
+    for (uint32_t rr = 0; rr < 2; ++rr) {
+        if (rr < todo) {
+            const uint32_t two = rr ? nw1 : nw0;
+            const uint64_t win = rr ? ((uint64_t)c1 | ((uint64_t)c2 << 32)) : ((uint64_t)c0 | ((uint64_t)c1 << 32));
+#pragma unroll
+            for (uint32_t j = 0; j < 2; ++j) {
+                const uint32_t piece = (two >> (16 * j)) & 0xFFFFu;
+                bool found = false;
+                for (uint32_t sh = 0; sh <= 2 * k; ++sh) // displacement sh - k
+                    found = found || (((uint32_t)(win >> (2 * (8 * j + sh))) & 0xFFFFu) == piece);
+                missing += found ? 0u : 1u;
+            }
         }
-        if (missing > k)
-            return false;
     }
-    return true;
+    if (missing > k)
+        return 0;
+    done += todo;
+    if (done >= n_rounds)
+        return 2;
+    rng = (rng & ~((0x7Fu << kPieceRoundsShift) | (7u << kPieceMissingShift))) | (done << kPieceRoundsShift) |
+          (missing << kPieceMissingShift);
+    return 1;
 }
 
 // Range code of an exact-table entry (.w):
@@ -1068,12 +1109,17 @@ __device__ __forceinline__ bool seed_sig_ok(const text64 &W, uint32_t sig, uint3
     return ((got ^ sig) & mask) == 0;
 }
 
-// (survivor, entry, offset) pairs wait in LDS until a wave has 64 of them: a key shared by twenty needles, or by eight
-// offsets of one, would otherwise keep one lane busy with checks while 63 idle
+// Work waits in LDS until a wave has 64 items of a kind: a key shared by twenty needles, a pair that needs all its
+// piece rounds, a seed hit that counts into four bands would otherwise keep one lane busy while 63 idle -- and the band
+// table's atomics, whose round trips to HBM are the longest latency in this kernel, would be issued a few lanes at a time.
 constexpr uint32_t kPairCap = 128;
-struct pair_queue // per wave
+struct pair_queue // per wave: (survivor, entry) pairs on their way through the checks
 {
     uint32_t t_lo[kPairCap], t_hi[kPairCap], val[kPairCap], rng[kPairCap], seg[kPairCap];
+};
+struct band_queue // per wave: (band key, diagonals hit) on their way into the band table
+{
+    uint32_t key_lo[kPairCap], key_hi[kPairCap], run_lo[kPairCap], run_hi[kPairCap];
 };
 
 struct band_chunk // this wave's chunk of the band list (wave-uniform registers)
@@ -1085,15 +1131,104 @@ struct band_chunk // this wave's chunk of the band list (wave-uniform registers)
 // sets whose wave-per-band verification wants every wave busy) leaves a dense list; later draws take growing chunks.
 constexpr uint32_t kDenseDraws = 4;
 
-// 64 (or the last few) pairs, one per lane: checks, then the bands they count into
-__device__ __forceinline__ void resolve_pairs(const resolve_params &R, const pair_queue &Q, uint32_t first, uint32_t n,
-                                              uint32_t lane, band_chunk &C, uint32_t &n_cand)
+// n (<= 64) queued band hits, one per lane: into the band table; the first arrival of a band appends it to the list
+__device__ __forceinline__ void insert_bands(const resolve_params &R, const band_queue &B, uint32_t first, uint32_t n,
+                                             uint32_t lane, band_chunk &C)
 {
-    bool emit = lane < n;
+    const bool act = lane < n;
+    unsigned long long bkey = 0, run = 0;
+    if (act) {
+        bkey = ((unsigned long long)B.key_hi[first + lane] << 32) | B.key_lo[first + lane];
+        run = ((unsigned long long)B.run_hi[first + lane] << 32) | B.run_lo[first + lane];
+    }
+    bool claimed = false;
+    uint32_t s2 = (uint32_t)mix64(bkey) & R.table_mask;
+    if (act) {
+        bool placed = false;
+        for (uint32_t tries = 0; tries < 8192 && !placed; ++tries) {
+            const unsigned long long o = atomicCAS(&R.band_tab[s2].x, kBandEmpty, bkey);
+            if (o == kBandEmpty) {
+                claimed = true;
+                placed = true;
+            } else if (o == bkey) {
+                placed = true;
+            } else {
+                s2 = (s2 + 1) & R.table_mask;
+            }
+        }
+        if (!placed)
+            atomicAdd(&R.counters[2], 1ull); // table full: the host starts over with more room
+        else if (R.overlap)
+            atomicAdd(&R.band_tab[s2].y, 1ull);
+        else
+            atomicAnd(&R.band_tab[s2].y, ~run);
+    }
+    const uint64_t mm = __ballot(claimed);
+    if (mm == 0)
+        return;
+    const uint32_t nn = __popcll(mm);
+    if (C.used + nn > C.size) { // close this chunk (unused tail invalid), draw the next
+        for (uint32_t q = C.used + lane; q < C.size; q += 64)
+            if (C.base + q < R.band_cap)
+                R.bands[C.base + q].val = kBandInvalid;
+        uint32_t next = C.size * 2 < kChunkMin ? kChunkMin : (C.size * 2 > kChunkMax ? kChunkMax : C.size * 2);
+        next = next < nn ? nn : next;
+        if (C.draws < kDenseDraws) {
+            next = nn;
+            ++C.draws;
+        }
+        unsigned long long b = 0;
+        if (lane == 0)
+            b = atomicAdd(&R.counters[3], (unsigned long long)next);
+        C.base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+        C.used = 0;
+        C.size = next;
+    }
+    if (claimed) {
+        const uint64_t idx = C.base + C.used + __popcll(mm & ((1ull << lane) - 1));
+        if (idx < R.band_cap) {
+            band_rec br;
+            br.slot = s2;
+            br.val = (uint32_t)(bkey >> 43) << 11;
+            br.seg = (uint32_t)((bkey & ((1ull << 43) - 1)) >> R.band_bits);
+            br.band = (uint32_t)(bkey & ((1ull << R.band_bits) - 1));
+            R.bands[idx] = br;
+        } else {
+            atomicAdd(&R.counters[2], 1ull); // band list full
+        }
+    }
+    C.used += nn;
+}
+
+struct resolve_wave // what a wave of resolve_kernel carries (wave-uniform)
+{
+    pair_queue *Q;
+    band_queue *B;
+    uint32_t qn, bn;
+    band_chunk C;
+    uint32_t n_cand;
+};
+
+__device__ __forceinline__ void queue_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// n (<= 64) pairs from the top of the queue, one per lane: one visit of the checks; pairs with rounds to go return to the
+// queue, pairs that are through become band hits
+__device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wave &S, uint32_t n, uint32_t lane)
+{
+    pair_queue &Q = *S.Q;
+    band_queue &B = *S.B;
+    S.qn -= n;
+    const uint32_t first = S.qn;
+    bool live = lane < n;
     uint64_t t = 0, seg = 0;
     uint32_t val = 0, rng = 0;
     int64_t sb = (int64_t)R.hay_begin, se = (int64_t)R.hay_end;
-    if (emit) {
+    if (live) {
         const uint32_t i = first + lane;
         t = ((uint64_t)Q.t_hi[i] << 32) | Q.t_lo[i];
         val = Q.val[i];
@@ -1104,104 +1239,89 @@ __device__ __forceinline__ void resolve_pairs(const resolve_params &R, const pai
             se = (int64_t)R.seg_offsets[seg + 1];
         }
     }
-    if (emit && !(rng & kRngRun) &&
-        !(((rng & kSeedChecked) || seed_intact(R, t, val, (rng >> 16) & 0xF, sb, se)) && pieces_plausible(R, t, val, sb, se)))
-        emit = false;
+    queue_sync(); // (every lane holds its pair before anything is written back)
+    bool through = live;
+    const uint32_t pat = val >> 11;
+    if (live && !(rng & kRngRun)) {
+        if (!(rng & kSeedChecked)) {
+            live = seed_intact(R, t, val, (rng >> 16) & 0xF, sb, se);
+            rng |= kSeedChecked;
+        }
+        through = live;
+        if (live && R.pieces_check) {
+            const uint32_t m = (uint32_t)R.m[pat], k = (uint32_t)R.k[pat];
+            if (pieces_apply(R, t, val, m, k, sb, se)) {
+                const uint32_t v = pieces_visit(R, t, val, rng, m, k);
+                live = v != 0;
+                through = v == 2;
+            }
+        }
+    }
+    // back into the queue: alive, not through
+    {
+        const bool back = live && !through;
+        const uint64_t mm = __ballot(back);
+        if (back) {
+            const uint32_t q = S.qn + __popcll(mm & ((1ull << lane) - 1));
+            Q.t_lo[q] = (uint32_t)t;
+            Q.t_hi[q] = (uint32_t)(t >> 32);
+            Q.val[q] = val;
+            Q.rng[q] = rng;
+            Q.seg[q] = (uint32_t)seg;
+        }
+        S.qn += __popcll(mm);
+    }
     // bands this pair counts into: those holding a diagonal of [d_lo, d_hi]; with overlapping bands also the one
     // before, if d_lo still lies in its k-wide extension
-    uint32_t pat = 0;
     int64_t b_cur = 0, b_last = -1, d_lo = 0, d_hi = 0;
-    if (emit) {
-        ++n_cand;
-        pat = val >> 11;
+    if (live && through) {
+        ++S.n_cand;
         d_hi = (int64_t)t - (int64_t)(val & 0x7FF) - sb + (int64_t)R.max_m;
-        d_lo = d_hi - (int64_t)(rng & 0x7FF);
+        d_lo = d_hi - (int64_t)((rng & kRngRun) ? (rng & 0x7FF) : 0u);
         b_cur = d_lo / (int64_t)R.Bw;
         b_last = d_hi / (int64_t)R.Bw;
         if (R.overlap && b_cur > 0 && d_lo - b_cur * (int64_t)R.Bw <= (int64_t)R.k[pat])
             --b_cur;
-    }
-    while (__ballot(b_cur <= b_last) != 0) {
-        bool claimed = false;
-        uint32_t bslot = 0;
-        if (b_cur <= b_last && (uint64_t)b_cur >> R.band_bits) {
+        if ((uint64_t)b_last >> R.band_bits) {
             atomicAdd(&R.counters[2], 1ull); // a haystack too long for the key layout: the host falls back
-            b_cur = b_last + 1;
+            b_last = b_cur - 1;
         }
-        if (b_cur <= b_last) {
+    }
+    for (;;) {
+        const bool have = b_cur <= b_last;
+        const uint64_t mm = __ballot(have);
+        if (mm == 0)
+            break;
+        if (have) {
             const unsigned long long bkey =
                 ((unsigned long long)pat << 43) | ((unsigned long long)seg << R.band_bits) | (unsigned long long)b_cur;
-            uint32_t s2 = (uint32_t)mix64(bkey) & R.table_mask;
-            bool placed = false;
-            for (uint32_t tries = 0; tries < 8192 && !placed; ++tries) {
-                const unsigned long long o = atomicCAS(&R.band_keys[s2], kBandEmpty, bkey);
-                if (o == kBandEmpty) {
-                    claimed = true;
-                    placed = true;
-                } else if (o == bkey) {
-                    placed = true;
-                } else {
-                    s2 = (s2 + 1) & R.table_mask;
-                }
-            }
-            if (placed) {
-                if (R.overlap) {
-                    atomicAdd(&R.band_val[s2], 1ull);
-                } else { // which diagonals of the band (Bw <= 64) are hit: the verification covers just those
-                    const int64_t b0 = b_cur * (int64_t)R.Bw;
-                    const uint32_t o_lo = (uint32_t)(d_lo > b0 ? d_lo - b0 : 0);
-                    const uint32_t o_hi = (uint32_t)(d_hi < b0 + (int64_t)R.Bw - 1 ? d_hi - b0 : (int64_t)R.Bw - 1);
-                    const unsigned long long run = o_hi - o_lo >= 63 ? ~0ull : ((1ull << (o_hi - o_lo + 1)) - 1);
-                    atomicOr(&R.band_val[s2], run << o_lo);
-                }
-            } else {
-                atomicAdd(&R.counters[2], 1ull); // table full: the host starts over with more room
-            }
-            bslot = s2;
+            // which diagonals of the band (Bw <= 64) are hit: the verification covers just those
+            const int64_t b0 = b_cur * (int64_t)R.Bw;
+            const uint32_t o_lo = (uint32_t)(d_lo > b0 ? d_lo - b0 : 0);
+            const uint32_t o_hi = (uint32_t)(d_hi < b0 + (int64_t)R.Bw - 1 ? d_hi - b0 : (int64_t)R.Bw - 1);
+            const unsigned long long run = (o_hi - o_lo >= 63 ? ~0ull : ((1ull << (o_hi - o_lo + 1)) - 1)) << o_lo;
+            const uint32_t q = S.bn + __popcll(mm & ((1ull << lane) - 1));
+            B.key_lo[q] = (uint32_t)bkey;
+            B.key_hi[q] = (uint32_t)(bkey >> 32);
+            B.run_lo[q] = (uint32_t)run;
+            B.run_hi[q] = (uint32_t)(run >> 32);
         }
-        const uint64_t mm = __ballot(claimed);
-        if (mm != 0) {
-            const uint32_t nn = __popcll(mm);
-            if (C.used + nn > C.size) { // close this chunk (unused tail invalid), draw the next
-                for (uint32_t q = C.used + lane; q < C.size; q += 64)
-                    if (C.base + q < R.band_cap)
-                        R.bands[C.base + q].val = kBandInvalid;
-                uint32_t next = C.size * 2 < kChunkMin ? kChunkMin : (C.size * 2 > kChunkMax ? kChunkMax : C.size * 2);
-                next = next < nn ? nn : next;
-                if (C.draws < kDenseDraws) {
-                    next = nn;
-                    ++C.draws;
-                }
-                unsigned long long b = 0;
-                if (lane == 0)
-                    b = atomicAdd(&R.counters[3], (unsigned long long)next);
-                C.base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
-                C.used = 0;
-                C.size = next;
-            }
-            if (claimed) {
-                const uint64_t idx = C.base + C.used + __popcll(mm & ((1ull << lane) - 1));
-                if (idx < R.band_cap) {
-                    band_rec br;
-                    br.slot = bslot;
-                    br.val = pat << 11;
-                    br.seg = (uint32_t)seg;
-                    br.band = (uint32_t)b_cur;
-                    R.bands[idx] = br;
-                } else {
-                    atomicAdd(&R.counters[2], 1ull); // band list full
-                }
-            }
-            C.used += nn;
+        S.bn += __popcll(mm);
+        queue_sync();
+        if (S.bn >= 64) {
+            S.bn -= 64;
+            insert_bands(R, B, S.bn, 64, lane, S.C);
+            queue_sync();
         }
         ++b_cur;
     }
+    queue_sync();
 }
 
 __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
 {
-    __shared__ pair_queue queues[4];
+    __shared__ pair_queue pair_queues[4];
+    __shared__ band_queue band_queues[4];
     unsigned long long n = R.counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&R.counters[8], n);
@@ -1210,14 +1330,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
     if (n > R.surv_cap)
         n = R.surv_cap;
     const uint32_t lane = threadIdx.x & 63;
-    pair_queue &Q = queues[threadIdx.x >> 6];
-    uint32_t qn = 0; // pairs waiting (wave-uniform)
-    band_chunk C;
-    C.base = 0;
-    C.used = 0;
-    C.size = 0;
-    C.draws = 0;
-    uint32_t n_cand = 0;
+    resolve_wave S;
+    S.Q = &pair_queues[threadIdx.x >> 6];
+    S.B = &band_queues[threadIdx.x >> 6];
+    S.qn = 0;
+    S.bn = 0;
+    S.C.base = 0;
+    S.C.used = 0;
+    S.C.size = 0;
+    S.C.draws = 0;
+    S.n_cand = 0;
+    pair_queue &Q = *S.Q;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride; // wave-uniform trip count: the queue and the appends are wave-collective
     for (uint64_t r = 0; r < rounds; ++r) {
@@ -1267,73 +1390,100 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                 W.ok = true;
             }
         }
-        uint32_t slot = ht_hash(key) & T.ht_mask;
-        while (__ballot(probing) != 0) {
-            // the probe sequence four slots at a time: one aligned 64-byte line, its four loads in flight together, so a
-            // key that twenty needles share costs five round trips to L2 instead of twenty
-            uint4 e4[4];
-            const uint32_t g0 = slot & ~3u;
-            if (probing) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    e4[j] = T.ht[g0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t val = 0, rng = 0;
-                bool have = false;
-                if (probing && g0 + j >= slot) {
-                    const uint4 e = e4[j];
-                    if (e.y == kHtEmpty) {
+        // the key's entries: one short directory probe per survivor ...
+        uint32_t first = 0, cnt = 0;
+        {
+            uint32_t slot = ht_hash(key) & T.ht_mask;
+            while (__ballot(probing) != 0) {
+                if (probing) {
+                    const uint4 d = T.ht[slot];
+                    if (d.z == 0) {
+                        probing = false; // (a level-1 false positive: no such key)
+                    } else if (d.x == key) {
+                        first = d.y;
+                        cnt = d.z;
                         probing = false;
-                    } else if (e.x == key) {
-                        have = true;
-                        val = e.y;
-                        rng = e.w;
-                        if (!(rng & kRngRun)) {
-                            const uint32_t r0 = rng & 0xF, ns = (rng >> 4) & 0x1F;
-                            const bool whole = (rng & kRngWhole) != 0;
-                            rng = r0 << 16; // (queued with the pair: where the key window sits in its seed)
-                            if (W.ok) { // does the rest of the seed match?  (registers only)
-                                if (!seed_sig_ok(W, e.z, r0, ns, R.key_len))
-                                    have = false;
-                                else if (whole)
-                                    rng = kSeedChecked;
-                            }
-                        }
-                    }
-                }
-                // queue the pairs of this step; 64 waiting pairs are resolved at once
-                const uint64_t mm = __ballot(have);
-                if (mm != 0) {
-                    if (have) {
-                        const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
-                        Q.t_lo[q] = (uint32_t)t;
-                        Q.t_hi[q] = (uint32_t)(t >> 32);
-                        Q.val[q] = val;
-                        Q.rng[q] = rng;
-                        Q.seg[q] = (uint32_t)seg;
-                    }
-                    qn += __popcll(mm);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (qn >= 64) {
-                        qn -= 64;
-                        resolve_pairs(R, Q, qn, 64, lane, C, n_cand);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    } else {
+                        slot = (slot + 1) & T.ht_mask;
                     }
                 }
             }
-            slot = (g0 + 4) & T.ht_mask;
+        }
+        // ... then the (survivor, entry) pairs of the whole wave are dealt to its lanes, 64 at a time: pair i belongs to the
+        // lane whose inclusive prefix sum of `cnt` is the first one above i
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= (uint32_t)o)
+                incl += up;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, 63));
+        for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+            const uint32_t i = p0 + lane;
+            bool have = i < total;
+            uint32_t owner = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint32_t v = (uint32_t)__shfl((int)incl, (int)(owner + step - 1));
+                if (v <= i)
+                    owner += step;
+            }
+            owner = owner > 63 ? 63 : owner;
+            const uint32_t o_incl = (uint32_t)__shfl((int)incl, (int)owner), o_cnt = (uint32_t)__shfl((int)cnt, (int)owner);
+            const uint32_t o_first = (uint32_t)__shfl((int)first, (int)owner);
+            const uint64_t o_t = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(t >> 32), (int)owner) << 32) |
+                                 (uint32_t)__shfl((int)(uint32_t)t, (int)owner);
+            const uint32_t o_seg = (uint32_t)__shfl((int)(uint32_t)seg, (int)owner);
+            text64 OW;
+            OW.lo = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(W.lo >> 32), (int)owner) << 32) |
+                    (uint32_t)__shfl((int)(uint32_t)W.lo, (int)owner);
+            OW.hi = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(W.hi >> 32), (int)owner) << 32) |
+                    (uint32_t)__shfl((int)(uint32_t)W.hi, (int)owner);
+            OW.ok = __shfl((int)W.ok, (int)owner) != 0;
+            uint32_t val = 0, rng = 0;
+            if (have) {
+                const uint4 e = R.entries[o_first + (i - (o_incl - o_cnt))];
+                val = e.x;
+                rng = e.z;
+                if (!(rng & kRngRun)) {
+                    const uint32_t r0 = rng & 0xF, ns = (rng >> 4) & 0x1F;
+                    const bool whole = (rng & kRngWhole) != 0;
+                    rng = r0 << 16; // (queued with the pair: where the key window sits in its seed)
+                    if (OW.ok) { // does the rest of the seed match?  (registers only)
+                        if (!seed_sig_ok(OW, e.y, r0, ns, R.key_len))
+                            have = false;
+                        else if (whole)
+                            rng |= kSeedChecked;
+                    }
+                }
+            }
+            // queue the pairs that are left; 64 waiting pairs are resolved at once
+            const uint64_t mm = __ballot(have);
+            if (mm != 0) {
+                if (have) {
+                    const uint32_t q = S.qn + __popcll(mm & ((1ull << lane) - 1));
+                    Q.t_lo[q] = (uint32_t)o_t;
+                    Q.t_hi[q] = (uint32_t)(o_t >> 32);
+                    Q.val[q] = val;
+                    Q.rng[q] = rng;
+                    Q.seg[q] = o_seg;
+                }
+                S.qn += __popcll(mm);
+                queue_sync();
+                while (S.qn >= 64)
+                    check_pairs(R, S, 64, lane);
+            }
         }
     }
-    if (qn != 0)
-        resolve_pairs(R, Q, 0, qn, lane, C, n_cand);
-    for (uint32_t q = C.used + lane; q < C.size; q += 64)
-        if (C.base + q < R.band_cap)
-            R.bands[C.base + q].val = kBandInvalid;
-    wave_count_add(R.counters + 5, n_cand);
+    while (S.qn != 0)
+        check_pairs(R, S, S.qn < 64 ? S.qn : 64, lane);
+    if (S.bn != 0)
+        insert_bands(R, *S.B, 0, S.bn, lane, S.C);
+    for (uint32_t q = S.C.used + lane; q < S.C.size; q += 64)
+        if (S.C.base + q < R.band_cap)
+            R.bands[S.C.base + q].val = kBandInvalid;
+    wave_count_add(R.counters + 5, S.n_cand);
 }
 
 // Reserve hit slots for a whole wave with ONE atomic: lane l gets `mine` consecutive slots starting at the returned index.
@@ -1399,9 +1549,8 @@ __global__ __launch_bounds__(256) void band_select_kernel(const verify_params P,
         if (i < n) {
             c = P.bands[i];
             if (c.val != kBandInvalid) {
-                const uint32_t cnt = (uint32_t)P.band_val[c.slot];
-                P.band_val[c.slot] = 0;
-                P.band_keys[c.slot] = kBandEmpty;
+                const uint32_t cnt = (uint32_t)band_value(P.band_tab[c.slot].y, true);
+                band_release(P.band_tab, c.slot);
                 keep = cnt >= (P.surplus ? (uint32_t)P.surplus[c.val >> 11] : 1u);
             }
         }
@@ -1435,11 +1584,9 @@ __device__ __forceinline__ bool decode_band(const verify_params &P, const band_r
     g.pat = c.val >> 11;
     unsigned long long v = 1;
     if (!P.preselected) {
-        v = P.band_val[c.slot];
-        if (consume) {
-            P.band_val[c.slot] = 0;
-            P.band_keys[c.slot] = kBandEmpty;
-        }
+        v = band_value(P.band_tab[c.slot].y, P.overlap != 0);
+        if (consume)
+            band_release(P.band_tab, c.slot);
         if (P.overlap ? (uint32_t)v < (P.surplus ? (uint32_t)P.surplus[g.pat] : 1u) : v == 0)
             return false;
     }
@@ -1654,10 +1801,8 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             ws = g.ws;
         }
         __builtin_amdgcn_wave_barrier();
-        if (gl == 0 && c.val != kBandInvalid && !P.preselected) { // ... then one of them gives the table slot back
-            P.band_val[c.slot] = 0;
-            P.band_keys[c.slot] = kBandEmpty;
-        }
+        if (gl == 0 && c.val != kBandInvalid && !P.preselected) // ... then one of them gives the table slot back
+            band_release(P.band_tab, c.slot);
         if (active && gl == 0)
             ++n_valid;
         const uint32_t nb = (uint32_t)((m + 31) >> 5);        // blocks of this needle

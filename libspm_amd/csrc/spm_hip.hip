@@ -41,10 +41,10 @@ struct filter_index
     uint64_t n_entries = 0;  // entries of the exact table after identical (key, needle) pairs were merged
     uint32_t max_range = 0;  // largest diagonal range of a merged entry
     uint32_t *d_bitmap = nullptr;
-    uint4 *d_ht = nullptr; // exact table: {key, val, seed signature, range code}
+    uint4 *d_ht = nullptr; // key directory: {key, first entry, entries, -}, open addressing, an empty slot has .z == 0
     // host copies, kept only by spm_hip_host_selftest (no device involved)
     std::vector<uint32_t> h_image;
-    std::vector<uint4> h_ht;
+    std::vector<uint4> h_ht; // (the directory)
 };
 
 static thread_local bool g_index_host_only = false;
@@ -78,6 +78,8 @@ struct spm_patterns
     uint8_t *d_surplus = nullptr;   // per needle: seeds - k (candidate merging); nullptr = no needle has k >= kMergeMinK
     uint8_t *d_ranks = nullptr;     // filterable sets: the needles' symbols, back to back (whole-seed check of a candidate)
     uint32_t *d_offsets = nullptr;  // ... and where each needle starts
+    uint32_t *d_needle_pk = nullptr;  // dna4 sets: the needles 2 bits per symbol, 16 per word (piece count of a candidate)
+    uint32_t *d_pk_offsets = nullptr; // ... and the first word of each
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
     uint32_t filter_max_range = 0; // largest diagonal range over all passes
@@ -85,7 +87,10 @@ struct spm_patterns
     std::vector<uint16_t> seed_q, seed_n, seed_off;
     std::vector<uint32_t> seed_first;
     uint16_t *d_seed_q = nullptr;
-    pass_entry *d_pass_tab = nullptr; // the passes' exact key tables, for resolve_kernel
+    pass_entry *d_pass_tab = nullptr; // the passes' key directories, for resolve_kernel
+    std::vector<uint4> h_entries;     // exact entries of all passes, grouped by key: {val = needle << 11 | offset, seed
+                                      // signature, range code, key}
+    uint4 *d_entries = nullptr;
     mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
     mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
 };
@@ -180,6 +185,7 @@ static bool layout_seeds(const spm_patterns *ps, uint32_t p, uint32_t q_floor, u
 static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
 {
     ps->fidx.clear();
+    ps->h_entries.clear();
     if ((ps->sigma != 4 && ps->sigma != 5 && ps->sigma != 15) || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 ||
         ps->n >= (1u << 21))
         return SPM_OK;
@@ -268,6 +274,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                     hipFree(F.d_ht);
                 }
                 ps->fidx.clear();
+    ps->h_entries.clear();
                 return SPM_OK; // too many passes to be worth it: brute force
             }
             filter_index F;
@@ -281,6 +288,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                     hipFree(G.d_ht);
                 }
                 ps->fidx.clear();
+    ps->h_entries.clear();
                 return SPM_OK;
             }
             ps->fidx.push_back(F);
@@ -298,6 +306,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
             hipFree(F.d_ht);
         }
         ps->fidx.clear();
+    ps->h_entries.clear();
     }
     return SPM_OK;
 }
@@ -474,16 +483,41 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     F.lds_words = (uint32_t)image.size();
     const uint32_t words = F.lds_words;
     const std::vector<uint32_t> &bitmap = image;
-    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, F.n_entries * 2));
+    // Exact level: a directory key -> (first entry, count) with open addressing, and the entries of a key side by side
+    // in one array (all passes share it).  A survivor costs one short directory probe; its entries -- a key that twenty
+    // needles share has twenty -- are then dealt to the lanes of the wave one pair each (resolve_kernel), instead of one
+    // lane walking a probe sequence while 63 wait.
+    {
+        std::vector<size_t> order(keys.size());
+        for (size_t i = 0; i < order.size(); ++i)
+            order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a].key < keys[b].key; });
+        std::vector<kv> k2(keys.size());
+        std::vector<uint16_t> r2(keys.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            k2[i] = keys[order[i]];
+            r2[i] = ranges[order[i]];
+        }
+        keys.swap(k2);
+        ranges.swap(r2);
+    }
+    size_t n_distinct = 0;
+    for (size_t i = 0; i < keys.size(); ++i)
+        n_distinct += (i == 0 || keys[i].key != keys[i - 1].key) ? 1 : 0;
+    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, n_distinct * 2));
     F.ht_mask = ht_size - 1;
-    // exact table: {key, val = pattern << 11 | offset, seed signature, range code}, val == kHtEmpty marks an empty slot
-    std::vector<uint4> ht(ht_size, make_uint4(0, kHtEmpty, 0, 0));
-    for (size_t i = 0; i < keys.size(); ++i) {
-        const kv &e = keys[i];
-        uint32_t slot = ht_hash(e.key) & F.ht_mask;
-        while (ht[slot].y != kHtEmpty)
+    std::vector<uint4> ht(ht_size, make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < keys.size();) {
+        size_t j = i;
+        while (j < keys.size() && keys[j].key == keys[i].key)
+            ++j;
+        uint32_t slot = ht_hash(keys[i].key) & F.ht_mask;
+        while (ht[slot].z != 0)
             slot = (slot + 1) & F.ht_mask;
-        ht[slot] = make_uint4(e.key, e.val, e.sig, ranges[i]);
+        ht[slot] = make_uint4(keys[i].key, (uint32_t)ps->h_entries.size(), (uint32_t)(j - i), 0);
+        for (size_t q = i; q < j; ++q)
+            ps->h_entries.push_back(make_uint4(keys[q].val, keys[q].sig, ranges[q], keys[q].key));
+        i = j;
     }
     if (g_index_host_only) {
         F.h_image = bitmap;
@@ -634,6 +668,11 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
                 pt.push_back(pass_entry{F.d_ht, F.ht_mask, 0});
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_pass_tab, pt.size() * sizeof(pass_entry)));
             SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_pass_tab, pt.data(), pt.size() * sizeof(pass_entry), hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_entries, std::max<size_t>(ps->h_entries.size(), 1) * sizeof(uint4)));
+            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_entries, ps->h_entries.data(), ps->h_entries.size() * sizeof(uint4),
+                                         hipMemcpyHostToDevice));
+            ps->h_entries.clear();
+            ps->h_entries.shrink_to_fit();
             const size_t nr = ps->ranks.size() + 64; // padded: resolve_kernel reads whole dwords around a seed
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_ranks, nr));
             SPM_HIP_CHECK(ctx, hipMemset(ps->d_ranks, 0, nr));
@@ -642,6 +681,25 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
                 SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
             SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t),
                                          hipMemcpyHostToDevice));
+            if (ps->sigma == 4) { // the same symbols 2 bits each, 16 per word, every needle from a word of its own
+                std::vector<uint32_t> pk, pk_off(ps->n, 0);
+                for (uint32_t p = 0; p < ps->n; ++p) {
+                    pk_off[p] = (uint32_t)pk.size();
+                    const uint8_t *nd = ps->ranks.data() + ps->offsets[p];
+                    const uint32_t m = (uint32_t)ps->m[p];
+                    for (uint32_t y = 0; y < m; y += 16) {
+                        uint32_t w = 0;
+                        for (uint32_t i = 0; i < 16 && y + i < m; ++i)
+                            w |= (uint32_t)(nd[y + i] & 3) << (2 * i);
+                        pk.push_back(w);
+                    }
+                }
+                pk.push_back(0);
+                SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_needle_pk, pk.size() * sizeof(uint32_t)));
+                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_needle_pk, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_pk_offsets, pk_off.size() * sizeof(uint32_t)));
+                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_pk_offsets, pk_off.data(), pk_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_seed_q, ps->seed_q.size() * sizeof(uint16_t)));
             SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_seed_q, ps->seed_q.data(), ps->seed_q.size() * sizeof(uint16_t),
                                          hipMemcpyHostToDevice));
@@ -671,7 +729,10 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     hipFree(p->d_surplus);
     hipFree(p->d_ranks);
     hipFree(p->d_offsets);
+    hipFree(p->d_needle_pk);
+    hipFree(p->d_pk_offsets);
     hipFree(p->d_pass_tab);
+    hipFree(p->d_entries);
     hipFree(p->d_seed_q);
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
@@ -876,8 +937,7 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
-    hipFree(ctx->d_band_keys);
-    hipFree(ctx->d_band_val);
+    hipFree(ctx->d_band_tab);
     delete ctx;
 }
 
@@ -1379,20 +1439,16 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
     if (ctx->band_slots >= slots && !ctx->band_dirty)
         return SPM_OK;
     if (ctx->band_slots < slots) {
-        if (ctx->d_band_keys) {
+        if (ctx->d_band_tab) {
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            hipFree(ctx->d_band_keys);
-            hipFree(ctx->d_band_val);
-            ctx->d_band_keys = nullptr;
-            ctx->d_band_val = nullptr;
+            hipFree(ctx->d_band_tab);
+            ctx->d_band_tab = nullptr;
             ctx->band_slots = 0;
         }
-        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_keys, slots * sizeof(unsigned long long)));
-        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_val, slots * sizeof(unsigned long long)));
+        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_tab, slots * sizeof(ulonglong2)));
         ctx->band_slots = slots;
     }
-    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_keys, 0xFF, ctx->band_slots * sizeof(unsigned long long), ctx->stream));
-    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_val, 0, ctx->band_slots * sizeof(unsigned long long), ctx->stream));
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_tab, 0xFF, ctx->band_slots * sizeof(ulonglong2), ctx->stream)); // all free
     ctx->band_dirty = false;
     return SPM_OK;
 }
@@ -1682,6 +1738,7 @@ int run_filter(const scan_args &A)
     R.counters = H->d_count;
     R.surv_cap = surv_cap;
     R.passes = ps->d_pass_tab;
+    R.entries = ps->d_entries;
     R.key_len = ps->filter_key_len;
     R.text = A.text->d;
     R.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
@@ -1700,8 +1757,9 @@ int run_filter(const scan_args &A)
     R.overlap = overlap ? 1u : 0u;
     R.max_m = ps->max_m;
     R.band_bits = 43 - seg_bits;
-    R.band_keys = ctx->d_band_keys;
-    R.band_val = ctx->d_band_val;
+    R.band_tab = ctx->d_band_tab;
+    R.needle_pk = ps->d_needle_pk;
+    R.pk_offsets = ps->d_pk_offsets;
     R.table_mask = (uint32_t)(band_slots - 1);
     R.bands = d_bands;
     R.band_cap = band_cap;
@@ -1724,8 +1782,7 @@ int run_filter(const scan_args &A)
     V.bands = d_bands;
     V.counters = H->d_count;
     V.band_cap = band_cap;
-    V.band_keys = ctx->d_band_keys;
-    V.band_val = ctx->d_band_val;
+    V.band_tab = ctx->d_band_tab;
     V.surplus = ps->d_surplus;
     V.Bw = Bw;
     V.overlap = overlap ? 1u : 0u;
@@ -2332,14 +2389,22 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
     auto level2 = [&](const filter_index &F, uint32_t key, uint32_t val) -> bool {
         uint32_t slot = ht_hash(key) & F.ht_mask;
         for (;;) {
-            const uint4 e = F.h_ht[slot];
-            if (e.y == kHtEmpty)
+            const uint4 d = F.h_ht[slot];
+            if (d.z == 0)
                 return false;
-            if (e.x == key && (e.y >> 11) == (val >> 11)) {
-                // the entry itself, or a run whose diagonal range covers this offset
-                const uint32_t x0 = e.y & 0x7FF, x = val & 0x7FF;
-                if (!(e.w & kRngRun) ? x == x0 : (x >= x0 && x <= x0 + (e.w & 0x7FF)))
-                    return true;
+            if (d.x == key) {
+                for (uint32_t q = 0; q < d.z; ++q) {
+                    const uint4 e = ps.h_entries[d.y + q];
+                    if (e.w != key)
+                        return false; // the entries of a key lie side by side
+                    if ((e.x >> 11) == (val >> 11)) {
+                        // the entry itself, or a run whose diagonal range covers this offset
+                        const uint32_t x0 = e.x & 0x7FF, x = val & 0x7FF;
+                        if (!(e.z & kRngRun) ? x == x0 : (x >= x0 && x <= x0 + (e.z & 0x7FF)))
+                            return true;
+                    }
+                }
+                return false;
             }
             slot = (slot + 1) & F.ht_mask;
         }
