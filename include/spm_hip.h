@@ -295,8 +295,10 @@ uint64_t spm_hip_mix64(uint64_t z);
 
 /* Host-only self-check of the seed index (no device, no context): builds the level-1 / level-2 tables exactly as
  * spm_hip_patterns_create does and verifies what the filter's losslessness rests on -- every indexed 16-symbol window of
- * every seed is found at both levels, every needle sits in exactly one pass, the stride fits every seed.
- * stats[8] = {passes, stride, keys, windows checked, windows missing, level-1 false positives, trials, hash variant}.
+ * every seed is found at both levels, every needle sits in exactly one pass (anchored sets: every seed has its one key
+ * in one pass, beginning with an anchor dimer of that pass), the stride fits every seed.
+ * stats[8] = {passes, stride, keys, windows checked, windows missing, level-1 false positives, trials,
+ *            hash variant | anchor dimers per pass << 8 (0: unanchored)}.
  * Returns SPM_OK iff nothing is missing. */
 int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, const uint32_t *offsets, uint32_t n_patterns,
                           const uint16_t *k, uint32_t sigma, uint64_t *stats);

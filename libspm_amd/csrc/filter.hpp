@@ -132,6 +132,8 @@ struct filter_params
     const uint32_t *bitmap;   // [bitmap_words]
     uint32_t span_budget;     // survivors one span may produce before it gives up
     uint32_t pass;            // which sub-batch of the needle set this launch filters for (survivor::pad)
+    uint32_t anchor_c, anchor_cm; // anchored passes: a window is looked up iff its leading dimer d = sym0 | sym1 << 2 has
+                                  // (d ^ anchor_c) & anchor_cm == 0
     survivor *surv;
     unsigned long long *counters; // [1] = survivor slots drawn, [6] = spans that gave up, [2] = hard overflow
     uint64_t surv_cap;
@@ -532,9 +534,68 @@ __device__ __forceinline__ void filter_words(const filter_params &P, const uint3
 }
 
 
+// ---- anchored passes (stride 1, needle sets of several passes) ------------------------------------------------------
+// The keys of the pass all begin with its anchor dimer (the host chose each seed's key window that way; a few passes
+// carry a pattern with a don't-care bit, i.e. two dimers), so only the text windows that begin with it -- 1 in 16 -- can
+// equal a key.  Which of a lane's 16 windows those are is computed bit-parallel on the packed word (9 VALU for 16
+// windows); the hash and the two LDS reads then run for the selected windows only, in a per-lane loop.  The unanchored
+// stride-1 kernel spends 14 VALU and two conflict-ridden LDS reads on EVERY window and saturates both the VALU and the
+// LDS.
+
+// bit 2 (d - 1) set: window d (1..16) of this word -- it starts at symbol d of (prev, w) -- begins with the anchor
+__device__ __forceinline__ uint32_t anchor_select(uint32_t w, uint32_t prev, uint32_t c, uint32_t cm)
+{
+    // (wave-uniform) the pattern's bits for the first and the second symbol, repeated for every symbol of a word
+    const uint32_t C0 = (c & 3u) * 0x55555555u, M0 = (cm & 3u) * 0x55555555u;
+    const uint32_t C1 = (c >> 2) * 0x55555555u, M1 = (cm >> 2) * 0x55555555u;
+    const uint32_t X = alignbit(w, prev, 2); // symbols 1..16: where the windows start
+    const uint32_t Y = alignbit(w, prev, 4); // symbols 2..17: their second symbols
+    uint32_t t = ((X ^ C0) & M0) | ((Y ^ C1) & M1); // a set bit: that bit of that symbol differs from the pattern
+    t |= t >> 1;
+    return ~t & 0x55555555u;
+}
+
+template <int NWD>
+__device__ __forceinline__ void filter_words_anchored(const filter_params &P, const uint32_t (&w)[NWD], const uint32_t (&prev)[NWD],
+                                                      uint64_t gbase, uint32_t lane, const uint32_t *lds)
+{
+    static_assert(NWD % 2 == 0 || NWD == 1, "words are taken in pairs");
+    const uint16_t *fp_tab = reinterpret_cast<const uint16_t *>(lds);
+    const uint16_t *disp_tab = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(lds) + P.chd_disp_off);
+#pragma unroll
+    for (int j = 0; j < NWD; j += 2) {
+        // the selected windows of two words in one mask: bit b = word j + (b & 1), window (b >> 1) + 1
+        uint32_t todo = anchor_select(w[j], prev[j], P.anchor_c, P.anchor_cm);
+        if (j + 1 < NWD)
+            todo |= anchor_select(w[j + 1 < NWD ? j + 1 : j], prev[j + 1 < NWD ? j + 1 : j], P.anchor_c, P.anchor_cm) << 1;
+        while (__ballot(todo != 0) != 0) {
+            const bool act = todo != 0;
+            const uint32_t b = act ? (uint32_t)__ffs(todo) - 1u : 0u;
+            todo &= todo - 1;
+            const uint32_t u = b & 1u, d = (b >> 1) + 1u;
+            const uint32_t wu = (j + 1 < NWD && u) ? w[j + 1 < NWD ? j + 1 : j] : w[j];
+            const uint32_t pu = (j + 1 < NWD && u) ? prev[j + 1 < NWD ? j + 1 : j] : prev[j];
+            const uint32_t key = (uint32_t)((((uint64_t)wu << 32) | pu) >> (2 * d));
+            const uint32_t x = chd_hash(key).x;
+            const uint32_t dsp = disp_tab[x >> P.chd_bucket_shift];
+            const uint32_t slot = ((x >> 3) + dsp * ((key | 1u) & 0xFFFFFFu)) & P.chd_slot_mask;
+            const uint32_t f = fp_tab[slot];
+            const bool hit = act && ((f ^ key ^ (key >> 16)) & 0xFFFFu) == 0;
+            if (__ballot(hit) != 0) { // rare: a survivor for resolve_kernel
+                if (__builtin_amdgcn_readfirstlane(cand_chunk_of(P, lds)[5]) != 0)
+                    return; // the span has given up
+                const uint64_t wpos = gbase + (uint64_t)(j + u) * 1024 + (uint64_t)lane * 16;
+                const int64_t ts = (int64_t)wpos - 16 + (int64_t)d;
+                const bool has = hit && ts >= (int64_t)P.lo && (uint64_t)ts + P.key_len <= P.hi;
+                emit_survivors(P, has, key, has ? (uint64_t)ts : 0, lane, lds);
+            }
+        }
+    }
+}
+
 // One group of UU consecutive 1-KiB chunks, already in registers.  chunk u of the group starts at text index
 // gbase + 1024*u; this lane holds its bytes [16*lane, 16*lane+16).
-template <int S, int UU, int HV, int SIG, bool KM>
+template <int S, int UU, int HV, int SIG, bool KM, bool AN = false>
 __device__ __forceinline__ void filter_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase,
                                              uint32_t &carry_in, uint32_t &carry_n, uint32_t lane,
                                              const uint32_t *lds, uint32_t idx_mask)
@@ -557,7 +618,10 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
             nv[u] = (nm << 16) | np;
         }
     }
-    filter_words<S, UU, HV, SIG, false, KM>(P, w, prev, nv, gbase, lane, lds, idx_mask);
+    if constexpr (AN)
+        filter_words_anchored<UU>(P, w, prev, gbase, lane, lds);
+    else
+        filter_words<S, UU, HV, SIG, false, KM>(P, w, prev, nv, gbase, lane, lds, idx_mask);
 }
 
 // Streaming structure: a wave owns spans of consecutive 1-KiB chunks; per iteration it works on a GROUP of U chunks
@@ -568,7 +632,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
 // which made the masked-key stride-2 variant spill to scratch inside the streaming loop (+31 % kernel time).
 // Stride 1 without key masks (C4-sized needle sets: LDS-bound at 16 windows per lane, see DESIGN) fits 128 VGPRs and may run
 // 16 waves per CU.
-template <int S, int U, bool NT, int HV, int SIG, bool KM>
+template <int S, int U, bool NT, int HV, int SIG, bool KM, bool AN = false>
 __global__ __launch_bounds__((S == 1 && !KM && SIG == 4) ? 1024 : 512) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
@@ -670,14 +734,14 @@ __global__ __launch_bounds__((S == 1 && !KM && SIG == 4) ? 1024 : 512) void seed
                 // scheduled well as they are; a barrier there only forces the packing to wait for all eight loads.)
                 if constexpr (S <= 2)
                     __builtin_amdgcn_sched_barrier(0);
-                filter_group<S, U, HV, SIG, KM>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
+                filter_group<S, U, HV, SIG, KM, AN>(P, cur, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
             }
         }
         // ---- ragged end ----
         for (; ch < c_end; ++ch) {
             uint4 one[1];
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
-            filter_group<S, 1, HV, SIG, KM>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
+            filter_group<S, 1, HV, SIG, KM, AN>(P, one, base0 + ch * 1024, carry_in, carry_n, lane, lds, idx_mask);
         }
         sp += n_waves;
     }

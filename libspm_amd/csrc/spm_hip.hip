@@ -28,6 +28,8 @@ using namespace spm_hip;
 // ----------------------------------------------------------------------------------------------------
 struct filter_index
 {
+    // anchored passes: every key begins with a dimer d (sym0 | sym1 << 2) with (d ^ anchor_c) & anchor_cm == 0; cm = 0: unanchored
+    uint32_t anchor_c = 0, anchor_cm = 0;
     bool ok = false;
     uint32_t stride = 0;
     uint32_t key_len = 16;
@@ -82,6 +84,7 @@ struct spm_patterns
     uint32_t *d_pk_offsets = nullptr; // ... and the first word of each
     uint32_t filter_stride = 0;
     uint32_t filter_key_len = 16;
+    bool filter_anchored = false; // stride 1, one key per seed, chosen to begin with an anchor dimer of its pass
     uint32_t filter_max_range = 0; // largest diagonal range over all passes
     // seed layout (filterable sets): needle p has seed_n[p] seeds of seed_q[p] symbols at seed_off[seed_first[p] + j]
     std::vector<uint16_t> seed_q, seed_n, seed_off;
@@ -109,8 +112,11 @@ static int env_int(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
-                           filter_index &F);
+struct seed_key // one indexed window: needle p, seed at offset o of the needle, window starting r symbols into the seed
+{
+    uint32_t p, o, r;
+};
+static int build_one_index(spm_ctx *ctx, spm_patterns *ps, const std::vector<seed_key> &items, uint32_t S, filter_index &F);
 
 // A symbol the 2-bit keys can hold: A, C, G, T.  dna5 (seqan3 ranks A0 C1 G2 N3 T4): everything but N; dna15 (A0 B1 C2 D3
 // G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T only.
@@ -257,42 +263,150 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
         const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
         ps->filter_stride = S;
         ps->filter_key_len = H;
-        uint32_t p0 = 0;
-        while (p0 < ps->n) {
-            uint64_t keys = 0;
-            uint32_t p1 = p0;
-            while (p1 < ps->n) {
-                const uint64_t add = (uint64_t)ps->seed_n[p1] * S;
-                if (keys + add > cap && p1 > p0)
-                    break;
-                keys += add;
-                ++p1;
-            }
-            if (ps->fidx.size() >= max_passes) {
-                for (filter_index &F : ps->fidx) {
-                    hipFree(F.d_bitmap);
-                    hipFree(F.d_ht);
+        // ---- which windows are indexed, and in which pass ----
+        std::vector<std::vector<seed_key>> pass_items;
+        std::vector<uint32_t> pass_anchor;
+        ps->filter_anchored = false;
+        const uint64_t n_passes0 = (n_seeds * S + cap - 1) / cap;
+        if (S == 1 && n_passes0 > 1 && ps->sigma == 4 && H == 16 && qmin > H && env_int("SPM_HIP_FILTER_ANCHOR", 1) != 0) {
+            // Anchored keys.  A set this large gets ONE key per seed (stride 1: every text window is looked up, in every
+            // pass) -- but which of the seed's q - H + 1 windows that is, is ours to choose.  Pass i takes only keys whose
+            // first two symbols (a "dimer", 4 bits: sym0 | sym1 << 2) match ITS anchor pattern: (dimer ^ c) & cm == 0, at
+            // first one dimer per pass (cm = 15).  The streaming kernel then looks up only the text windows that begin
+            // with the anchor -- 1 in 16 -- instead of all: a window beginning with anything else cannot equal a key of the
+            // pass.  Lossless: an intact seed still has its key window in the text.  Each seed goes to a pass in which it
+            // has such a window among its first 16 (fewest choices first, least-loaded pass).  A seed that finds no place
+            // (with 7 passes about one in 10 000) widens a pass's pattern by one don't-care bit -- that pass looks up
+            // 2 in 16 windows.
+            struct cand
+            {
+                uint32_t p, o, dimers, n_ok; // dimers: bit d set = one of the windows r <= min(15, q - H) begins with d
+            };
+            std::vector<cand> seeds;
+            seeds.reserve(n_seeds);
+            for (uint32_t p = 0; p < ps->n; ++p) {
+                const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
+                const uint32_t q = ps->seed_q[p];
+                for (uint32_t j = 0; j < ps->seed_n[p]; ++j) {
+                    const uint32_t o = ps->seed_off[ps->seed_first[p] + j];
+                    uint32_t dm = 0;
+                    for (uint32_t r = 0; r <= std::min<uint32_t>(15, q - H); ++r)
+                        dm |= 1u << ((pat[o + r] & 3u) | ((pat[o + r + 1] & 3u) << 2));
+                    seeds.push_back({p, o, dm, 0});
                 }
-                ps->fidx.clear();
-    ps->h_entries.clear();
-                return SPM_OK; // too many passes to be worth it: brute force
             }
+            auto dimer_set = [](uint32_t c, uint32_t cm) {
+                uint32_t set = 0;
+                for (uint32_t d = 0; d < 16; ++d)
+                    set |= (((d ^ c) & cm) == 0 ? 1u : 0u) << d;
+                return set;
+            };
+            const uint32_t np_min = (uint32_t)((n_seeds + cap - 1) / cap);
+            for (uint32_t np = np_min; np <= np_min + 1 && pass_items.empty(); ++np) {
+                std::vector<uint32_t> pc(np), pcm(np, 15u), sets(np);
+                for (uint32_t i = 0; i < np; ++i) {
+                    pc[i] = (5u * i + 3u) & 15u; // (a fixed shuffle of the dimers: neighbouring passes differ in both symbols)
+                    sets[i] = dimer_set(pc[i], pcm[i]);
+                }
+                for (cand &c : seeds) {
+                    c.n_ok = 0;
+                    for (uint32_t i = 0; i < np; ++i)
+                        c.n_ok += (c.dimers & sets[i]) ? 1u : 0u;
+                }
+                std::vector<uint32_t> order(seeds.size());
+                for (uint32_t i = 0; i < order.size(); ++i)
+                    order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return seeds[x].n_ok < seeds[y].n_ok; });
+                std::vector<std::vector<uint32_t>> members(np);
+                bool all = true;
+                for (uint32_t idx : order) {
+                    const cand &c = seeds[idx];
+                    uint32_t best = np;
+                    for (uint32_t i = 0; i < np; ++i)
+                        if ((c.dimers & sets[i]) && members[i].size() < cap && (best == np || members[i].size() < members[best].size()))
+                            best = i;
+                    if (best == np) { // no place: widen the narrowest pattern that then takes this seed
+                        uint32_t bbit = 0;
+                        for (uint32_t i = 0; i < np; ++i) {
+                            if (members[i].size() >= cap)
+                                continue;
+                            for (uint32_t bit = 1; bit < 16; bit <<= 1)
+                                if ((pcm[i] & bit) && (c.dimers & dimer_set(pc[i], pcm[i] & ~bit)) &&
+                                    (best == np || __builtin_popcount(pcm[i]) > __builtin_popcount(pcm[best]))) {
+                                    best = i;
+                                    bbit = bit;
+                                }
+                        }
+                        if (best == np) {
+                            all = false;
+                            break;
+                        }
+                        pcm[best] &= ~bbit;
+                        sets[best] = dimer_set(pc[best], pcm[best]);
+                    }
+                    members[best].push_back(idx);
+                }
+                if (!all)
+                    continue;
+                pass_items.resize(np);
+                for (uint32_t i = 0; i < np; ++i) {
+                    for (uint32_t idx : members[i]) {
+                        const cand &c = seeds[idx];
+                        const uint8_t *pat = ps->ranks.data() + ps->offsets[c.p];
+                        uint32_t r = 0;
+                        while (!((sets[i] >> ((pat[c.o + r] & 3u) | ((pat[c.o + r + 1] & 3u) << 2))) & 1u))
+                            ++r;
+                        pass_items[i].push_back({c.p, c.o, r});
+                    }
+                    pass_anchor.push_back(pc[i] | (pcm[i] << 4));
+                }
+                ps->filter_anchored = true;
+            }
+        }
+        if (pass_items.empty()) {
+            uint32_t p0 = 0;
+            while (p0 < ps->n) {
+                uint64_t keys = 0;
+                uint32_t p1 = p0;
+                while (p1 < ps->n) {
+                    const uint64_t add = (uint64_t)ps->seed_n[p1] * S;
+                    if (keys + add > cap && p1 > p0)
+                        break;
+                    keys += add;
+                    ++p1;
+                }
+                pass_items.emplace_back();
+                pass_anchor.push_back(0u); // (no bit of the dimer is compared: every window is looked up)
+                for (uint32_t p = p0; p < p1; ++p)
+                    for (uint32_t j = 0; j < ps->seed_n[p]; ++j)
+                        for (uint32_t r = 0; r < S; ++r)
+                            pass_items.back().push_back({p, ps->seed_off[ps->seed_first[p] + j], r});
+                p0 = p1;
+            }
+        }
+        auto drop_all = [&]() {
+            for (filter_index &G : ps->fidx) {
+                hipFree(G.d_bitmap);
+                hipFree(G.d_ht);
+            }
+            ps->fidx.clear();
+            ps->h_entries.clear();
+        };
+        if (pass_items.size() > max_passes)
+            return SPM_OK; // too many passes to be worth it: brute force
+        for (size_t pi = 0; pi < pass_items.size(); ++pi) {
             filter_index F;
             F.key_len = H;
-            int rc = build_one_index(ctx, ps, p0, p1, S, F);
+            F.anchor_c = pass_anchor[pi] & 15u;
+            F.anchor_cm = pass_anchor[pi] >> 4;
+            int rc = build_one_index(ctx, ps, pass_items[pi], S, F);
             if (rc != SPM_OK)
                 return rc;
             if (!F.ok) {
-                for (filter_index &G : ps->fidx) {
-                    hipFree(G.d_bitmap);
-                    hipFree(G.d_ht);
-                }
-                ps->fidx.clear();
-    ps->h_entries.clear();
+                drop_all();
                 return SPM_OK;
             }
             ps->fidx.push_back(F);
-            p0 = p1;
         }
         ps->filter_max_range = 0;
         for (const filter_index &F : ps->fidx) {
@@ -311,8 +425,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
     return SPM_OK;
 }
 
-static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uint32_t p_end, uint32_t S,
-                           filter_index &F)
+static int build_one_index(spm_ctx *ctx, spm_patterns *ps, const std::vector<seed_key> &items, uint32_t S, filter_index &F)
 {
     F.ok = false;
     struct kv
@@ -321,13 +434,12 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, uint32_t p_begin, uin
     };
     std::vector<kv> keys;
     auto code = [&](uint8_t c) -> uint32_t { return key_code(ps->sigma, c); };
-    for (uint32_t p = p_begin; p < p_end; ++p) {
-        const uint32_t q = ps->seed_q[p];
-        const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-        for (uint32_t j = 0; j < ps->seed_n[p]; ++j) {
-            const uint32_t o = ps->seed_off[ps->seed_first[p] + j];
-            for (uint32_t r = 0; r < S; ++r) {
-                // window seed[r, r+H) -- inside the seed because S <= q - H + 1
+    {
+        {
+            for (const seed_key &it : items) {
+                const uint32_t p = it.p, o = it.o, r = it.r, q = ps->seed_q[p];
+                const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
+                // window seed[r, r+H) -- inside the seed because r <= q - H
                 uint32_t key = 0;
                 for (uint32_t i = 0; i < F.key_len; ++i)
                     key |= code(pat[o + r + i]) << (2 * i);
@@ -1559,6 +1671,8 @@ int run_filter(const scan_args &A)
     P.n_probes = F.n_probes;
     P.bitmap = F.d_bitmap;
     P.pass = (uint32_t)fi;
+    P.anchor_c = F.anchor_c;
+    P.anchor_cm = F.anchor_cm;
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
     const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
@@ -1703,7 +1817,28 @@ int run_filter(const scan_args &A)
     case 8: LAUNCH_FILTER(8, 8); break;
     case 4: LAUNCH_FILTER(4, 8); break;
     case 2: LAUNCH_FILTER(2, 4); break;
-    default: LAUNCH_FILTER(1, 2); break;
+    default:
+        if (F.anchor_cm != 0 && F.hash_variant == 2 && ps->sigma == 4 && !short_keys) {
+            // anchored pass: few windows per lane are looked up, so a lane can hold more text
+            const int au = env_int("SPM_HIP_FILTER_ANCHOR_U", 4);
+#define LAUNCH_ANCHORED(UU)                                                                                            \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_kernel<1, UU, true, 2, 4, false, true>,                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_kernel<1, UU, true, 2, 4, false, true>), dim3(grid), dim3(threads), lds,       \
+                           ctx->stream, P);                                                                            \
+    } while (0)
+            if (au >= 8)
+                LAUNCH_ANCHORED(8);
+            else if (au >= 4)
+                LAUNCH_ANCHORED(4);
+            else
+                LAUNCH_ANCHORED(2);
+#undef LAUNCH_ANCHORED
+        } else {
+            LAUNCH_FILTER(1, 2);
+        }
+        break;
     }
 #undef LAUNCH_FILTER2
 #undef LAUNCH_FILTER3
@@ -2436,6 +2571,27 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
                 if (!key_symbol(sigma, ps.ranks[ps.offsets[p] + o + i]))
                     return SPM_E_INVALID;
         }
+        if (ps.filter_anchored) {
+            // every seed has ONE key, in one pass, and that key begins with an anchor dimer of the pass (so the streaming
+            // kernel, which looks up only such windows, meets it)
+            const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
+            for (uint32_t j = 0; j < sn; ++j) {
+                const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
+                uint32_t found = 0;
+                for (const filter_index &F : ps.fidx)
+                    for (uint32_t r = 0; r + ps.filter_key_len <= q && r < 16; ++r) {
+                        uint32_t key = 0;
+                        for (uint32_t i = 0; i < ps.filter_key_len; ++i)
+                            key |= key_code(sigma, pat[o + r + i]) << (2 * i);
+                        if ((((key & 0xF) ^ F.anchor_c) & F.anchor_cm) == 0 && level1(F, key) && level2(F, key, (p << 11) | (o + r)))
+                            ++found;
+                    }
+                ++checked;
+                if (found < 1)
+                    ++missing;
+            }
+            continue;
+        }
         const uint64_t mine = (uint64_t)sn * S;
         while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
             if (in_pass != ps.fidx[fi].n_keys)
@@ -2459,6 +2615,9 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
                     ++missing;
             }
     }
+    uint64_t anchor_sum = 0; // dimers looked up, over all passes
+    for (const filter_index &F : ps.fidx)
+        anchor_sum += 1ull << (4 - __builtin_popcount(F.anchor_cm));
     stats[3] = checked;
     stats[4] = missing;
     // false-positive rate of level 1 on pseudo-random keys (first pass)
@@ -2471,7 +2630,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
                   : 0;
     stats[5] = fp;
     stats[6] = trials;
-    stats[7] = ps.fidx[0].hash_variant;
+    stats[7] = ps.fidx[0].hash_variant | (ps.filter_anchored ? anchor_sum << 8 : 0);
     return missing ? SPM_E_INVALID : SPM_OK;
 }
 

@@ -19,6 +19,8 @@ def _selftest(spm, algo, needles, k, sigma=4):
                                               ks.ctypes.data_as(C.POINTER(C.c_uint16)), sigma, stats)
     names = ["passes", "stride", "keys", "checked", "missing", "fp", "trials", "hash_variant"]
     st = dict(zip(names, [int(x) for x in stats]))
+    st["anchor_dimers"] = st["hash_variant"] >> 8
+    st["hash_variant"] &= 0xFF
     st["key_len"] = st["stride"] >> 32
     st["stride"] &= 0xFFFFFFFF
     return rc, st
@@ -46,10 +48,19 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     rc, st = _selftest(spm, spm.ALGO_MYERS, big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)], 3)
     assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (3, 2, 160000)
     assert st["hash_variant"] == 2
-    # a C4-sized set: 400 000 seeds at stride 1 in 7 passes
-    rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(100000)], 3)
+    # a C4-sized set: 400 000 seeds at stride 1, one key per seed.  Anchored: every seed's key begins with the dimer of
+    # its pass (the streaming kernel looks up only the text windows that begin with it); a few passes take two dimers
+    c4 = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(100000)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
+    assert rc == 0 and st["missing"] == 0 and (st["stride"], st["keys"], st["checked"]) == (1, 400000, 400000)
+    assert st["passes"] == 7 and st["hash_variant"] == 2 and 7 <= st["anchor_dimers"] <= 14  # (dimers over all passes)
+    os.environ["SPM_HIP_FILTER_ANCHOR"] = "0"
+    try:
+        rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
+    finally:
+        del os.environ["SPM_HIP_FILTER_ANCHOR"]
     assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (7, 1, 400000)
-    assert st["hash_variant"] == 2
+    assert st["hash_variant"] == 2 and st["anchor_dimers"] == 0
     # mixed lengths and k: the stride follows the shortest seed
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
