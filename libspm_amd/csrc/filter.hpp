@@ -633,7 +633,7 @@ __device__ __forceinline__ void filter_group(const filter_params &P, const uint4
 // Stride 1 without key masks (C4-sized needle sets: LDS-bound at 16 windows per lane, see DESIGN) fits 128 VGPRs and may run
 // 16 waves per CU.
 template <int S, int U, bool NT, int HV, int SIG, bool KM, bool AN = false>
-__global__ __launch_bounds__((S == 1 && !KM && SIG == 4) ? 1024 : 512) void seed_filter_kernel(const filter_params P)
+__global__ __launch_bounds__(((S == 1 && !KM && SIG == 4) || (S == 2 && U == 2)) ? 1024 : 512) void seed_filter_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
     // ---- stage the level-1 table in LDS (once per workgroup; the grid is persistent) ----

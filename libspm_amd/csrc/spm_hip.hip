@@ -1679,8 +1679,11 @@ int run_filter(const scan_args &A)
                             !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
     // measured best: 8 waves per CU on the 1-byte text when HBM binds, 16 on the 2-bit shadow and at stride 1 with
     // 16-symbol keys (LDS-bound: C4 25.8 vs 29.1 ms; the other stride-1/2 variants need more than 128 VGPRs)
-    const bool wide_ok = use_packed || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
-                                        !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
+    // stride 2: two chunks per group (16 windows per lane) need < 128 VGPRs, so 16 waves per CU hide the LDS round trips
+    // (C5: 0.53 -> 0.46 ms; four chunks per group hold 167 VGPRs at 8 waves)
+    const bool narrow2 = F.stride == 2 && !use_packed && env_int("SPM_HIP_FILTER_S2_U", 2) == 2;
+    const bool wide_ok = use_packed || narrow2 || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
+                                                   !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
     const uint32_t threads = (uint32_t)std::max(
         64, std::min(wide_ok ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", wide_ok ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave
@@ -1816,7 +1819,12 @@ int run_filter(const scan_args &A)
     case 16: LAUNCH_FILTER(16, 8); break;
     case 8: LAUNCH_FILTER(8, 8); break;
     case 4: LAUNCH_FILTER(4, 8); break;
-    case 2: LAUNCH_FILTER(2, 4); break;
+    case 2:
+        if (narrow2)
+            LAUNCH_FILTER2(2, 2);
+        else
+            LAUNCH_FILTER(2, 4);
+        break;
     default:
         if (F.anchor_cm != 0 && F.hash_variant == 2 && ps->sigma == 4 && !short_keys) {
             // anchored pass: few windows per lane are looked up, so a lane can hold more text
