@@ -1902,12 +1902,24 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         const uint32_t t_end = n_cols + nb - 1;                    // steps until the last block has seen the last column
         // wave-uniform trip count: the longest group decides
         uint32_t t_wave = active ? t_end : 0u;
-        for (int o = 32; o >= (int)G; o >>= 1)
+        // ... and the steps in which EVERY block of every band of the wave has a column of its window: [t_lo, t_hi)
+        uint32_t t_lo = active ? nb - 1 : 0u, t_hi = active ? n_cols : 0xFFFFFFFFu;
+        for (int o = 32; o >= (int)G; o >>= 1) {
             t_wave = max(t_wave, (uint32_t)__shfl_xor((int)t_wave, o));
+            t_lo = max(t_lo, (uint32_t)__shfl_xor((int)t_lo, o));
+            t_hi = min(t_hi, (uint32_t)__shfl_xor((int)t_hi, o));
+        }
         t_wave = (uint32_t)__builtin_amdgcn_readfirstlane(t_wave);
-        const uint8_t *my_text = tw + skew - gl; // column t - gl of this lane = my_text[t]
-        uint32_t sym_next = mine ? my_text[gl] : 0u; // column 0 (clamped reads below keep every index inside the window)
-        for (uint32_t t = 0; t < t_wave; ++t) {
+        t_lo = (uint32_t)__builtin_amdgcn_readfirstlane(t_lo);
+        t_hi = (uint32_t)__builtin_amdgcn_readfirstlane(t_hi);
+        t_hi = t_hi > t_wave ? t_wave : t_hi;
+        t_lo = t_lo > t_hi ? t_hi : t_lo;
+        uint32_t sym_next = mine ? tw[skew] : 0u; // column 0 (clamped reads below keep every index inside the window)
+        // One step of one block.  CHECKED: the lane may have no column at this step (the pipeline fills and drains, or a
+        // shorter band shares the wave).  The steps in between -- nearly all -- run without exec-mask changes and with
+        // the match mask picked by bit selects instead of compare / cndmask chains: a band is a serial chain of ~1400
+        // steps, one wave per SIMD, so the scan pays for every instruction and every VALU -> SALU hand-over of a step.
+        auto step = [&](uint32_t t, auto checked, auto dna4) {
             const uint32_t ho_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ho, 0x138, 0xF, 0xF, false);
             const uint32_t col = t - gl; // wraps for t < gl: then col >= n_cols
             const uint32_t sym = sym_next;
@@ -1916,12 +1928,19 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 nc = nc < n_cols ? nc : 0u;
                 sym_next = tw[skew + nc];
             }
-            if (mine && col < n_cols) {
-                const uint32_t lo2 = (sym & 1u) ? e1 : e0, hi2 = (sym & 1u) ? e3 : e2;
-                uint32_t Eq = (sym & 2u) ? hi2 : lo2;
-                if (P.sigma != 4)
+            if (!decltype(checked)::value || (mine && col < n_cols)) {
+                uint32_t Eq;
+                if constexpr (decltype(dna4)::value) {
+                    const uint32_t s0 = (uint32_t)((int32_t)(sym << 31) >> 31), s1 = (uint32_t)((int32_t)(sym << 30) >> 31);
+                    const uint32_t lo2 = (e1 & s0) | (e0 & ~s0), hi2 = (e3 & s0) | (e2 & ~s0);
+                    Eq = (hi2 & s1) | (lo2 & ~s1);
+                    Eq = sym < 4 ? Eq : 0u;
+                } else {
+                    const uint32_t lo2 = (sym & 1u) ? e1 : e0, hi2 = (sym & 1u) ? e3 : e2;
+                    Eq = (sym & 2u) ? hi2 : lo2;
                     Eq = sym < 4 ? Eq : (sym == 4 ? e4 : 0u);
-                Eq = sym < P.sigma ? Eq : 0u;
+                    Eq = sym < P.sigma ? Eq : 0u;
+                }
                 const uint32_t hin = gl == 0 ? 0u : ho_up;
                 const uint32_t hp = hin & 1u, hn = hin >> 1;
                 const uint32_t Xv = Eq | Mv;
@@ -1936,13 +1955,23 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 score += (int32_t)op - (int32_t)on;
-                if (is_last && score <= (int32_t)k && col >= first_slot_col) {
+                if (is_last && mine && score <= (int32_t)k && col >= first_slot_col && col < n_cols) {
                     hb[col - first_slot_col] = (uint16_t)(score + 1);
                     any_hit = true;
                 }
             }
-        }
-        (void)my_text;
+        };
+        uint32_t t = 0;
+        for (; t < t_lo; ++t)
+            step(t, std::true_type{}, std::false_type{});
+        if (P.sigma == 4)
+            for (; t < t_hi; ++t)
+                step(t, std::false_type{}, std::true_type{});
+        else
+            for (; t < t_hi; ++t)
+                step(t, std::false_type{}, std::false_type{});
+        for (; t < t_wave; ++t)
+            step(t, std::true_type{}, std::false_type{});
         // ---- emission: the lanes of a group share its slots; wave-converged appends ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

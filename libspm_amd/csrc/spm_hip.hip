@@ -1357,7 +1357,11 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 template <int G>
 void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid, hipStream_t s)
 {
-    const uint32_t threads = 256;
+    // One wave per workgroup: a scan leaves a few thousand long bands, i.e. far fewer busy waves than the GPU has SIMDs,
+    // and each is a serial chain ~1400 steps long.  With four-wave workgroups filled in order, the dispatcher packed the
+    // busy waves four to a SIMD on a third of the CUs and left the rest idle.
+    const uint32_t threads = (uint32_t)std::max(64, std::min(256, env_int("SPM_HIP_VERIFY_WAVE_THREADS", 64)));
+    grid.x *= 256 / threads;
     const uint32_t n_slots = 2 * V.max_k + 1 + V.max_span;
     // text window of one candidate: cold start |P| + k symbols before the first end position, then the end positions
     V.wave_text = ((max_m + V.max_k + n_slots + 16 + 15) & ~15u) + 16;
