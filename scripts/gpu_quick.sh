@@ -11,6 +11,7 @@ fi
 for w in ${BENCH:-}; do
   extra="--no-other-configs"
   [ $w = c4 ] && extra="$extra --steps 3 --warmup 1 --packed-steps 0"
+  [ $w = reads100 ] && extra="$extra --steps 3 --warmup 1 --packed-steps 0"
   [ $w = c5 ] && extra="--steps 10 --warmup 2"
   [ $w = c3r ] && extra="$extra --steps 5 --warmup 2 --packed-steps 0"
   [ $w = c3r8 ] && { w=c3r; extra="$extra --steps 5 --warmup 2 --packed-steps 0 --repeat-needle-every 8"; }
