@@ -1184,6 +1184,7 @@ struct pair_queue // per wave: (survivor, entry) pairs on their way through the 
 struct band_queue // per wave: (band key, diagonals hit) on their way into the band table
 {
     uint32_t key_lo[kPairCap], key_hi[kPairCap], run_lo[kPairCap], run_hi[kPairCap];
+    uint32_t elect[128]; // insert_bands: which lane of the batch speaks for a band
 };
 
 struct band_chunk // this wave's chunk of the band list (wave-uniform registers)
@@ -1196,15 +1197,36 @@ struct band_chunk // this wave's chunk of the band list (wave-uniform registers)
 constexpr uint32_t kDenseDraws = 4;
 
 // n (<= 64) queued band hits, one per lane: into the band table; the first arrival of a band appends it to the list
-__device__ __forceinline__ void insert_bands(const resolve_params &R, const band_queue &B, uint32_t first, uint32_t n,
+__device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue &B, uint32_t first, uint32_t n,
                                              uint32_t lane, band_chunk &C)
 {
-    const bool act = lane < n;
+    bool act = lane < n;
     unsigned long long bkey = 0, run = 0;
-    if (act) {
+    if (act)
         bkey = ((unsigned long long)B.key_hi[first + lane] << 32) | B.key_lo[first + lane];
-        run = ((unsigned long long)B.run_hi[first + lane] << 32) | B.run_lo[first + lane];
+    // Hits of the same band inside the batch (the sampled windows of one needle in one repeat stretch) go to the table
+    // as ONE: every lane names itself in a small LDS table under its band's hash, whoever is left standing there speaks
+    // for the lanes with the same band, which OR their diagonals into its queue entry.  (Global atomics run at the memory
+    // channels, ~12 per ns over the whole device: they are what the band table costs.)
+    if (!R.overlap) {
+        const uint32_t h = (uint32_t)mix64(bkey) & 127u;
+        if (act)
+            B.elect[h] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t w = act ? B.elect[h] : lane;
+        const unsigned long long wkey = ((unsigned long long)B.key_hi[first + w] << 32) | B.key_lo[first + w];
+        const bool follower = act && w != lane && wkey == bkey;
+        if (follower) {
+            atomicOr(&B.run_lo[first + w], B.run_lo[first + lane]);
+            atomicOr(&B.run_hi[first + w], B.run_hi[first + lane]);
+            act = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    if (act)
+        run = ((unsigned long long)B.run_hi[first + lane] << 32) | B.run_lo[first + lane];
     bool claimed = false;
     uint32_t s2 = (uint32_t)mix64(bkey) & R.table_mask;
     if (act) {
