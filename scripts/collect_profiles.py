@@ -28,7 +28,7 @@ def short(name):
 # the driver-style bench line with every config
 shutil.copy(f"{src}/bench_default.json", f"{dst}/bench_default.json")
 # per-workload kernel statistics (rocprofv3 --kernel-trace --stats) + the durations of the last calls of each kernel
-for w in ("c3", "c2", "c4", "c5", "c3r"):
+for w in ("c3", "c2", "c4", "c5", "c3r", "reads100"):
     f = newest(f"{src}/trace_{w}/**/*_kernel_stats.csv")
     if f:
         shutil.copy(f, f"{dst}/{w}_kernel_stats.csv")

@@ -8,8 +8,8 @@ say() { echo "== $* ==" | tee -a $OUT/progress.log; }
 B="python3 $R/bench.py --no-cpu-baseline --brute-sample-mib 0 --packed-steps 0 --no-other-configs"
 say "default bench line (all configs)"
 timeout -k 10 600 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -5 $OUT/bench_default.err; exit 1; }
-for W in c3 c2 c4 c5 c3r; do
-  extra="--steps 10 --warmup 3"; [ $W = c4 ] && extra="--steps 3 --warmup 1"; [ $W = c3r ] && extra="--steps 5 --warmup 2"
+for W in c3 c2 c4 c5 c3r reads100; do
+  extra="--steps 10 --warmup 3"; [ $W = c4 ] && extra="--steps 3 --warmup 1"; [ $W = reads100 ] && extra="--steps 3 --warmup 1"; [ $W = c3r ] && extra="--steps 5 --warmup 2"
   say "kernel trace $W"
   cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- $B --workload $W $extra > $OUT/trace_$W.log 2>&1 || { tail -5 $OUT/trace_$W.log; exit 1; }
 done
