@@ -1075,8 +1075,8 @@ __device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t,
 // from the seed -- the seed sits in the part the needle shares with the text, what differs is at the other end -- and a
 // pair that is neither rejected nor through goes back into the wave's queue: on a repeat-rich text 85 % of the pairs are
 // rejected in the first visit, and the other lanes of the wave do not wait for the 15 % that need all the rounds.
-// Progress lives in the pair's `rng` word: rounds done (bits 20..26), pieces missing (27..29).
-constexpr uint32_t kPieceRoundsShift = 20, kPieceMissingShift = 27;
+// Progress lives in the pair's `rng` word: rounds done (bits 21..27), pieces missing (28..30).
+constexpr uint32_t kPieceRoundsShift = 21, kPieceMissingShift = 28;
 
 __device__ __forceinline__ bool pieces_apply(const resolve_params &P, uint64_t t, uint32_t val, uint32_t m, uint32_t k, int64_t hay_b,
                                              int64_t hay_e)
@@ -1130,7 +1130,7 @@ __device__ __forceinline__ uint32_t pieces_visit(const resolve_params &P, uint64
 }
 
 // Range code of an exact-table entry (.w):
-//   kRngSingle | r | ns << 4 [| kRngWhole]
+//   kRngSingle | r (5 bits) | ns << 5 [| kRngWhole]
 //                 the key sits at this one offset of the needle; its window starts r symbols into its seed; .z = signature:
 //                 the first ns (<= 16) symbols of the rest of the seed; kRngWhole: that IS the whole rest
 //   kRngRun | span
@@ -1158,13 +1158,15 @@ __device__ __forceinline__ uint32_t syms16(const text64 &W, uint32_t first) // 1
     return (uint32_t)(W.lo >> (2 * first)) | (first ? (uint32_t)(W.hi << (2 * (32 - first)) ) : 0u);
 }
 
-// the first n (<= 16) symbols of the seed's rest -- r before the key window, then those after it -- against the text
+// the first n (<= 16) symbols of the seed's rest -- the (up to 16) symbols right before the key window, r of them if the
+// window starts r < 16 symbols into its seed, then those after it -- against the text
 __device__ __forceinline__ bool seed_sig_ok(const text64 &W, uint32_t sig, uint32_t r, uint32_t n, uint32_t H)
 {
     if (n == 0)
         return true;
-    const uint32_t nl = r < n ? r : n; // symbols taken from before the window: text [t - r, t - r + nl)
-    uint32_t got = nl ? syms16(W, 16 - r) : 0u;
+    const uint32_t rb = r < 16 ? r : 16; // symbols of the seed before the window that the signature starts with
+    const uint32_t nl = rb < n ? rb : n; // ... of which it holds the first nl: text [t - rb, t - rb + nl)
+    uint32_t got = nl ? syms16(W, 16 - rb) : 0u;
     if (nl < 16) {
         got &= (1u << (2 * nl)) - 1;
         got |= syms16(W, 16 + H) << (2 * nl);
@@ -1330,7 +1332,7 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
     const uint32_t pat = val >> 11;
     if (live && !(rng & kRngRun)) {
         if (!(rng & kSeedChecked)) {
-            live = seed_intact(R, t, val, (rng >> 16) & 0xF, sb, se);
+            live = seed_intact(R, t, val, (rng >> 16) & 0x1F, sb, se);
             rng |= kSeedChecked;
         }
         through = live;
@@ -1533,7 +1535,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                 val = e.x;
                 rng = e.z;
                 if (!(rng & kRngRun)) {
-                    const uint32_t r0 = rng & 0xF, ns = (rng >> 4) & 0x1F;
+                    const uint32_t r0 = rng & 0x1F, ns = (rng >> 5) & 0x1F;
                     const bool whole = (rng & kRngWhole) != 0;
                     rng = r0 << 16; // (queued with the pair: where the key window sits in its seed)
                     if (OW.ok) { // does the rest of the seed match?  (registers only)

@@ -275,12 +275,13 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
             // first one dimer per pass (cm = 15).  The streaming kernel then looks up only the text windows that begin
             // with the anchor -- 1 in 16 -- instead of all: a window beginning with anything else cannot equal a key of the
             // pass.  Lossless: an intact seed still has its key window in the text.  Each seed goes to a pass in which it
-            // has such a window among its first 16 (fewest choices first, least-loaded pass).  A seed that finds no place
-            // (with 7 passes about one in 10 000) widens a pass's pattern by one don't-care bit -- that pass looks up
+            // has such a window among its first 32 (fewest choices first, least-loaded pass).  A seed that finds no place
+            // (seeds of 37 symbols, 22 windows, 7 passes: a few in a million) widens a pass's pattern by one don't-care bit -- that pass looks up
             // 2 in 16 windows.
+            constexpr uint32_t kAnchorWindows = 32; // (an entry records where its window sits in the seed in 5 bits)
             struct cand
             {
-                uint32_t p, o, dimers, n_ok; // dimers: bit d set = one of the windows r <= min(15, q - H) begins with d
+                uint32_t p, o, dimers, n_ok; // dimers: bit d set = one of the windows r <= min(31, q - H) begins with d
             };
             std::vector<cand> seeds;
             seeds.reserve(n_seeds);
@@ -290,7 +291,7 @@ static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
                 for (uint32_t j = 0; j < ps->seed_n[p]; ++j) {
                     const uint32_t o = ps->seed_off[ps->seed_first[p] + j];
                     uint32_t dm = 0;
-                    for (uint32_t r = 0; r <= std::min<uint32_t>(15, q - H); ++r)
+                    for (uint32_t r = 0; r <= std::min<uint32_t>(kAnchorWindows - 1, q - H); ++r)
                         dm |= 1u << ((pat[o + r] & 3u) | ((pat[o + r + 1] & 3u) << 2));
                     seeds.push_back({p, o, dm, 0});
                 }
@@ -447,13 +448,13 @@ static int build_one_index(spm_ctx *ctx, spm_patterns *ps, const std::vector<see
                 // first 16 of them, 2 bits each.  With the key that is the whole seed when q <= key_len + 16, so the
                 // resolve kernel checks "the seed occurs here unchanged" in registers (filter.hpp, seed_sig_ok)
                 uint32_t sig = 0, ns = 0;
-                for (uint32_t i = 0; i < r && ns < 16; ++i, ++ns)
+                for (uint32_t i = r > 16 ? r - 16 : 0; i < r && ns < 16; ++i, ++ns) // (the 16 symbols next to the window)
                     sig |= code(pat[o + i]) << (2 * ns);
                 for (uint32_t i = r + F.key_len; i < q && ns < 16; ++i, ++ns)
                     sig |= code(pat[o + i]) << (2 * ns);
                 // range code of a single entry: where the window sits in its seed (r), how many rest symbols the
                 // signature holds (ns), and whether that is the whole rest (filter.hpp, kRngSingle)
-                const uint32_t meta = kRngSingle | (r & 0xF) | (ns << 4) | (ns == q - F.key_len ? kRngWhole : 0u);
+                const uint32_t meta = kRngSingle | (r & 0x1F) | (ns << 5) | (ns == q - F.key_len ? kRngWhole : 0u);
                 keys.push_back({key, (p << 11) | (o + r), sig, meta});
             }
         }
@@ -2591,7 +2592,7 @@ extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, cons
                 const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
                 uint32_t found = 0;
                 for (const filter_index &F : ps.fidx)
-                    for (uint32_t r = 0; r + ps.filter_key_len <= q && r < 16; ++r) {
+                    for (uint32_t r = 0; r + ps.filter_key_len <= q && r < 32; ++r) {
                         uint32_t key = 0;
                         for (uint32_t i = 0; i < ps.filter_key_len; ++i)
                             key |= key_code(sigma, pat[o + r + i]) << (2 * i);
