@@ -95,6 +95,7 @@ struct spm_patterns
                                       // signature, range code, key}
     uint4 *d_entries = nullptr;
     mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
+    mutable bool scanned = false;     // the hints come from at least one completed filter scan
     mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
 };
 
@@ -1623,7 +1624,9 @@ int run_filter(const scan_args &A)
     // (repeat-rich texts) pays for what earlier scans of this needle set actually reported
     uint64_t want_seen = std::min<uint64_t>(band_cap * (2 * kmax + 1 + max_span), std::max<uint64_t>(H->cap, 1));
     if (!A.seen_full)
-        want_seen = std::min<uint64_t>(want_seen, std::max<uint64_t>(1u << 18, 4 * ps->hit_hint));
+        // (the first scan of a needle set knows nothing yet: room for 4 M hits -- a 64 MiB memset, 10 us -- rather than a
+        // set that a repeat-rich text fills up, which costs a second run of the whole scan)
+        want_seen = std::min<uint64_t>(want_seen, ps->scanned ? std::max<uint64_t>(1u << 18, 4 * ps->hit_hint) : (1ull << 22));
     uint64_t seen_slots = 1u << 16;
     while (seen_slots < 2 * want_seen)
         seen_slots <<= 1;
@@ -2146,6 +2149,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             patterns->cand_hint = std::max<uint64_t>(patterns->cand_hint, c[1]);
             patterns->hit_hint = std::max<uint64_t>(patterns->hit_hint, c[0]);
             patterns->band_hint = std::max<uint64_t>(patterns->band_hint, c[3]);
+            patterns->scanned = true;
         }
         if (c[0] > H->cap) {
             // more hits than the caller's buffer takes: that is the caller's overflow (SPM_E_OVERFLOW from the views,
