@@ -984,6 +984,18 @@ struct resolve_params
     uint64_t band_cap;
     const uint32_t *needle_pk;      // dna4 sets: the needles 2 bits per symbol, 16 symbols per word (pack16's bit order)
     const uint32_t *pk_offsets;     // first word of every needle in needle_pk
+    // Exact sets whose needles are their own (single) seed: a pair that passed the whole-seed check IS an occurrence and
+    // is reported from here -- no band, no verification launch (C2: Shift-Or |P| = 32).
+    uint32_t exact_hits;
+    uint32_t report_begin;          // 1: report begin = end - |P| (the exact matchers)
+    uint64_t scan_begin, scan_end;  // owned: last symbol index in [scan_begin, scan_end)
+    uint64_t pos_offset;
+    const uint32_t *seg_owned;
+    unsigned long long *seen;
+    uint32_t seen_mask;
+    spm_hit *hits;
+    unsigned long long *hit_counter, *overflow;
+    uint64_t hit_cap;
 };
 
 // Band table slot: .x = key (kBandEmpty = all ones: free), .y = value kept so that a free slot is ALL ONES (one memset
@@ -1289,6 +1301,50 @@ __device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue
     C.used += nn;
 }
 
+// Reserve hit slots for a whole wave with ONE atomic: lane l gets `mine` consecutive slots starting at the returned index.
+// (One atomic per end-position slot and wave, as the brute-force kernels do it, serialises on the counter's address at
+// ~100/us: a repeat-rich text reports millions of hits.)  Call with the wave converged.
+__device__ __forceinline__ unsigned long long wave_reserve_hits(unsigned long long *counter, uint32_t mine)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o)
+            incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    unsigned long long base = 0;
+    if (total != 0) {
+        if (lane == 0)
+            base = atomicAdd(counter, (unsigned long long)total);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+    }
+    return base + (incl - mine);
+}
+
+// one key per reported hit in the scan's dedupe set; true if this is the first report of (pattern, end)
+__device__ __forceinline__ bool seen_insert_raw(unsigned long long *seen, uint32_t seen_mask, unsigned long long *overflow,
+                                                uint32_t pat, int64_t e)
+{
+    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
+    uint32_t slot = (uint32_t)(mix64(key)) & seen_mask;
+    // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means more hits than
+    // it was sized for: flag it, the host starts over with a larger one
+    for (uint32_t tries = 0; tries < 512; ++tries) {
+        const unsigned long long old = atomicCAS(&seen[slot], ~0ull, key);
+        if (old == ~0ull)
+            return true;
+        if (old == key)
+            return false;
+        slot = (slot + 1) & seen_mask;
+    }
+    atomicAdd(overflow, 1ull);
+    return false;
+}
+
 struct resolve_wave // what a wave of resolve_kernel carries (wave-uniform)
 {
     pair_queue *Q;
@@ -1362,6 +1418,30 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
     // bands this pair counts into: those holding a diagonal of [d_lo, d_hi]; with overlapping bands also the one
     // before, if d_lo still lies in its k-wide extension
     int64_t b_cur = 0, b_last = -1, d_lo = 0, d_hi = 0;
+    if (R.exact_hits) { // (wave-uniform; such sets have no merged run entries)
+        bool fresh = false;
+        int64_t e = 0;
+        if (live && through) {
+            ++S.n_cand;
+            e = (int64_t)t - (int64_t)(val & 0x7FF) + (int64_t)R.m[pat]; // exclusive end of the occurrence
+            int64_t own_b = (int64_t)R.scan_begin, own_e = (int64_t)R.scan_end;
+            if (R.seg_offsets) {
+                own_b = R.seg_owned ? sb + (int64_t)R.seg_owned[seg] : sb;
+                own_e = se;
+            }
+            fresh = e >= own_b + 1 && e <= own_e && seen_insert_raw(R.seen, R.seen_mask, R.overflow, pat, e);
+        }
+        const unsigned long long idx = wave_reserve_hits(R.hit_counter, fresh ? 1u : 0u);
+        if (fresh && idx < R.hit_cap) {
+            spm_hit h;
+            h.pos = (R.report_begin ? (uint64_t)(e - (int64_t)R.m[pat]) : (uint64_t)e) + R.pos_offset;
+            h.pattern = pat;
+            h.score = 0;
+            R.hits[idx] = h;
+        }
+        queue_sync();
+        return;
+    }
     if (live && through) {
         ++S.n_cand;
         d_hi = (int64_t)t - (int64_t)(val & 0x7FF) - sb + (int64_t)R.max_m;
@@ -1574,47 +1654,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
     wave_count_add(R.counters + 5, S.n_cand);
 }
 
-// Reserve hit slots for a whole wave with ONE atomic: lane l gets `mine` consecutive slots starting at the returned index.
-// (One atomic per end-position slot and wave, as the brute-force kernels do it, serialises on the counter's address at
-// ~100/us: a repeat-rich text reports millions of hits.)  Call with the wave converged.
-__device__ __forceinline__ unsigned long long wave_reserve_hits(unsigned long long *counter, uint32_t mine)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-        if (lane >= (uint32_t)o)
-            incl += up;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    unsigned long long base = 0;
-    if (total != 0) {
-        if (lane == 0)
-            base = atomicAdd(counter, (unsigned long long)total);
-        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
-    }
-    return base + (incl - mine);
-}
-
 // one key per reported hit in the scan's dedupe set; true if this is the first report of (pattern, end)
 __device__ __forceinline__ bool seen_insert(const verify_params &P, uint32_t pat, int64_t e)
 {
-    const unsigned long long key = ((unsigned long long)pat << 40) | (unsigned long long)e;
-    uint32_t slot = (uint32_t)(mix64(key)) & P.seen_mask;
-    // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means more hits than
-    // it was sized for: flag it, the host starts over with a larger one
-    for (uint32_t tries = 0; tries < 512; ++tries) {
-        const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
-        if (old == ~0ull)
-            return true;
-        if (old == key)
-            return false;
-        slot = (slot + 1) & P.seen_mask;
-    }
-    atomicAdd(P.overflow, 1ull);
-    return false;
+    return seen_insert_raw(P.seen, P.seen_mask, P.overflow, pat, e);
 }
 
 // Sets with surplus seeds (k >= kMergeMinK): most bands hold a single chance match of a short key and are NOT verified.

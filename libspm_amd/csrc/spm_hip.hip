@@ -96,6 +96,7 @@ struct spm_patterns
     uint4 *d_entries = nullptr;
     mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
     mutable bool scanned = false;     // the hints come from at least one completed filter scan
+    mutable int exact_whole = -1;     // 1: k = 0 and every needle is its own single seed (decided at the first scan)
     mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
 };
 
@@ -1637,9 +1638,23 @@ int run_filter(const scan_args &A)
     int rc = ensure_scratch(ctx, surv_bytes + seen_bytes + band_bytes + ovf_bytes);
     if (rc != SPM_OK)
         return rc;
-    rc = ensure_band_table(ctx, band_slots);
-    if (rc != SPM_OK)
-        return rc;
+    // Exact sets whose needles are their own single seed (k = 0, no `N`, e.g. Shift-Or / Horspool sets): the whole-seed check
+    // of the resolve kernel is the whole comparison, so it reports the hits itself -- no band table, no verification launch.
+    // (Not for needles that are repeats: their merged index entries skip the per-offset check.)
+    bool exact_hits = ps->max_k == 0 && !overlap && ps->filter_max_range == 0 && ps->d_ranks &&
+                      env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) != 0 && env_int("SPM_HIP_EXACT_FROM_RESOLVE", 1) != 0;
+    if (exact_hits && ps->exact_whole < 0) {
+        bool whole = true;
+        for (uint32_t p = 0; p < ps->n && whole; ++p)
+            whole = ps->seed_n[p] == 1 && ps->seed_q[p] == (uint32_t)ps->m[p];
+        ps->exact_whole = whole ? 1 : 0;
+    }
+    exact_hits = exact_hits && ps->exact_whole == 1;
+    if (!exact_hits) {
+        rc = ensure_band_table(ctx, band_slots);
+        if (rc != SPM_OK)
+            return rc;
+    }
     survivor *d_surv = (survivor *)ctx->d_scratch;
     unsigned long long *d_seen = (unsigned long long *)((uint8_t *)ctx->d_scratch + surv_bytes);
     band_rec *d_bands = (band_rec *)((uint8_t *)d_seen + seen_bytes);
@@ -1651,7 +1666,8 @@ int run_filter(const scan_args &A)
         W.d_ovf = d_ovf;
     }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
-    ctx->band_dirty = true; // until the verification has consumed every band of this scan
+    if (!exact_hits)
+        ctx->band_dirty = true; // until the verification has consumed every band of this scan
 
     filter_params P{};
     P.text = A.text->d;
@@ -1911,6 +1927,18 @@ int run_filter(const scan_args &A)
     R.band_tab = ctx->d_band_tab;
     R.needle_pk = ps->d_needle_pk;
     R.pk_offsets = ps->d_pk_offsets;
+    R.exact_hits = exact_hits ? 1u : 0u;
+    R.report_begin = ps->is_myers() ? 0 : 1;
+    R.scan_begin = A.begin;
+    R.scan_end = A.end;
+    R.pos_offset = A.opts.pos_offset;
+    R.seg_owned = A.d_seg_owned;
+    R.seen = d_seen;
+    R.seen_mask = (uint32_t)(seen_slots - 1);
+    R.hits = H->d_hits;
+    R.hit_counter = H->d_count;
+    R.overflow = H->d_count + 2;
+    R.hit_cap = H->cap;
     R.table_mask = (uint32_t)(band_slots - 1);
     R.bands = d_bands;
     R.band_cap = band_cap;
@@ -1964,7 +1992,9 @@ int run_filter(const scan_args &A)
         V.band_counter = 10;
         V.preselected = 1;
     }
-    if (use_wave) {
+    if (exact_hits) {
+        // (the resolve kernel reported the hits)
+    } else if (use_wave) {
         // one verification is a ~1400-step serial chain: enough waves that every band gets its own right away
         launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
     } else {
