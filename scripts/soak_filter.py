@@ -18,7 +18,14 @@ for it in range(iters):
     if sigma == 5:
         T[T == 3] = 4
         T[rng.integers(0, n, 100)] = 3
-    n_pat = int(rng.choice([200, 3000, 9000, 16000]))
+    if it % 4 == 1:  # repeat stretches: microsatellites and low-complexity runs, ~1 % of the text
+        for _ in range(n // 13000):
+            o = int(rng.integers(0, n - 300)); ln = int(rng.integers(16, 257))
+            unit = rng.integers(0, 4, int(rng.integers(1, 7)), dtype=np.uint8)
+            if sigma == 5:
+                unit[unit == 3] = 4
+            T[o:o + ln] = np.resize(unit, ln)
+    n_pat = int(rng.choice([200, 3000, 9000, 16000, 40000]))
     m = int(rng.choice([48, 52, 60, 64, 80, 100, 150]))
     k = int(rng.integers(0, min(4, m // 12)))
     offs = rng.integers(0, n - m - 8, n_pat)
@@ -31,7 +38,8 @@ for it in range(iters):
             nd[rng.integers(0, m)] = rng.choice([0, 1, 2, 4] if sigma == 5 else [0, 1, 2, 3])
         needles.append(nd)
     text = ctx.upload(T, sigma=sigma)
-    ps = ctx.patterns(S.ALGO_MYERS, needles, k=k, sigma=sigma)
+    algo = S.ALGO_SHIFTOR if (k == 0 and it % 2 == 0) else S.ALGO_MYERS  # (exact sets: hits reported by the resolve kernel)
+    ps = ctx.patterns(algo, needles, k=k, sigma=sigma)
     if not ps.filterable:
         print(it, "not filterable", m, k)
         continue
