@@ -1220,8 +1220,8 @@ __device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue
         bkey = ((unsigned long long)B.key_hi[first + lane] << 32) | B.key_lo[first + lane];
     // Hits of the same band inside the batch (the sampled windows of one needle in one repeat stretch) go to the table
     // as ONE: every lane names itself in a small LDS table under its band's hash, whoever is left standing there speaks
-    // for the lanes with the same band, which OR their diagonals into its queue entry.  (Global atomics run at the memory
-    // channels, ~12 per ns over the whole device: they are what the band table costs.)
+    // for the lanes with the same band, which OR their diagonals into its queue entry.  (Worth 2 % on a text with many
+    // needles inside repeats; the table's compare-and-swap round trips are the longest waits of this kernel.)
     if (!R.overlap) {
         const uint32_t h = (uint32_t)mix64(bkey) & 127u;
         if (act)
