@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <cstdio>
 #include <string>
 #include <utility>
@@ -75,6 +76,8 @@ struct spm_hits
     uint64_t band_cap = 0;
     uint64_t n = 0;
     bool counted = false;
+    bool hook_final = false;          // the caller's after-launch work (scan_impl) ran on the final hit list ...
+    unsigned long long fan_count = 0; // ... and counted this much into counter slot 12
     bool sorted_host = false;
     std::vector<spm_hit> host;
     spm_scan_stats stats{};

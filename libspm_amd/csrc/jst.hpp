@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256) void jst_emit_kernel(jst_dev J, jst_emit_out O
 struct jst_fan_params
 {
     const spm_hit *hits;
-    uint64_t n_hits;
+    uint64_t n_hits;                         // segment hits, if the host knows their number ...
+    const unsigned long long *n_hits_dev;    // ... else where the scan counts them (launched before the host has read it)
+    uint64_t hit_cap;                        //     and the capacity of `hits`
     const uint64_t *ctx_off;
     uint64_t n_ctx;
     const uint32_t *ctx_block, *ctx_owned;
@@ -467,10 +469,18 @@ struct jst_fan_params
 // atomic on the single counter cost 0.6 ms for 10^6 records).
 __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
+    uint64_t n_hits = F.n_hits;
+    if (F.n_hits_dev) {
+        const unsigned long long n = *F.n_hits_dev;
+        n_hits = n < F.hit_cap ? n : F.hit_cap;
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (n_hits + stride - 1) / stride; // wave-uniform trip count: the slot reservation is wave-collective
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+    const uint64_t t = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // pass 1: which context, and how many haplotypes share it
-    bool live = t < F.n_hits;
+    bool live = t < n_hits;
     spm_hit hit{};
     uint64_t c = 0, local = 0, jr = 0;
     uint32_t id = 0, members = 0, h_lo = 0, h_hi = 0;
@@ -514,7 +524,7 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
         base = atomicAdd(F.out_count, (unsigned long long)total);
     base = __shfl(base, 0);
     if (!live || members == 0)
-        return;
+        continue;
     // pass 2: report the hit for every haplotype of the group, in haplotype coordinates
     unsigned long long slot = base + (incl - members);
     const uint64_t j = J.jb + jr;
@@ -534,6 +544,7 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
             F.out[slot] = o;
         }
         ++slot;
+    }
     }
 }
 
@@ -568,6 +579,7 @@ struct spm_jst
     // (record buffers of the searches are recycled through the context: a 200 MB hipMalloc / hipFree pair per search
     // cost ~0.3 ms)
     unsigned long long *d_fan_count = nullptr;
+    uint64_t seg_hit_hint = 0; // most segment hits a search has seen (sizes the grid of the fan-out launched behind the scan)
     hipEvent_t fan_ev[2] = {nullptr, nullptr};
 
     spm_hip::jst_dev dev() const
@@ -988,9 +1000,54 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
         return SPM_OK;
     }
     spm_hits *seg = nullptr;
+    for (size_t i = 0; i < ctx->jst_pool.size(); ++i)
+        if (ctx->jst_pool[i].second == out_cap) {
+            R->d = static_cast<spm_jst_hit *>(ctx->jst_pool[i].first);
+            ctx->jst_pool.erase(ctx->jst_pool.begin() + (long)i);
+            break;
+        }
+    if (!R->d)
+        SPM_HIP_CHECK(ctx, hipMalloc(&R->d, out_cap * sizeof(spm_jst_hit)));
+    R->cap = out_cap;
+    if (!J->d_fan_count) {
+        SPM_HIP_CHECK(ctx, hipMalloc(&J->d_fan_count, 8));
+        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[0]));
+        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[1]));
+    }
+    hipEvent_t e0 = J->fan_ev[0], e1 = J->fan_ev[1];
+    jst_fan_params F{};
+    F.ctx_off = J->d_ctx_off;
+    F.n_ctx = J->n_ctx;
+    F.ctx_block = J->d_ctx_block;
+    F.ctx_owned = J->d_ctx_owned;
+    F.ctx_base = J->d_ctx_base;
+    F.local_id = J->d_local_id;
+    F.m = patterns->d_m;
+    F.report_begin = patterns->is_myers() ? 0 : 1;
+    F.out = R->d;
+    F.out_cap = out_cap;
+    // The fan-out is launched right behind the scan's kernels, before the host has read the scan's counters: it takes the
+    // number of segment hits from the device and counts its records into a spare slot of the scan's counter block, so one
+    // read-back serves both (a second host round trip per search cost ~35 us of an idle GPU).  If the scan has to go on
+    // after that read-back (overflow, fallback), the fan-out is simply run again below.
+    const std::function<int(spm_hits *)> fan_hook = [&](spm_hits *h) -> int {
+        jst_fan_params G = F;
+        G.hits = h->d_hits;
+        G.n_hits = 0;
+        G.n_hits_dev = h->d_count;
+        G.hit_cap = h->cap;
+        G.out_count = h->d_count + 12;
+        const uint64_t expect = std::max<uint64_t>(1u << 16, 2 * J->seg_hit_hint);
+        SPM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(jst_fanout_kernel, dim3((unsigned)std::min<uint64_t>((expect + 255) / 256, (uint64_t)ctx->n_cu * 64)),
+                           dim3(256), 0, ctx->stream, J->dev(), G);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        SPM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+        return SPM_OK;
+    };
     // the verification stage skips end positions inside a context's left context (the fan-out would drop them)
     int rc = scan_impl(ctx, J->ctx_text, 0, J->ctx_bytes, patterns, &o, nullptr, nullptr, nullptr, J->n_ctx, &seg,
-                       J->d_ctx_off, J->d_ctx_owned);
+                       J->d_ctx_off, J->d_ctx_owned, &fan_hook);
     if (rc != SPM_OK)
         return rc;
     std::unique_ptr<spm_hits, void (*)(spm_hits *)> S(seg, spm_hip_hits_destroy);
@@ -1010,47 +1067,29 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
     J->stats.fell_back = ss.fell_back;
     J->stats.candidates = ss.n_candidates;
     J->stats.bands = ss.n_bands;
-    for (size_t i = 0; i < ctx->jst_pool.size(); ++i)
-        if (ctx->jst_pool[i].second == out_cap) {
-            R->d = static_cast<spm_jst_hit *>(ctx->jst_pool[i].first);
-            ctx->jst_pool.erase(ctx->jst_pool.begin() + (long)i);
-            break;
+    J->seg_hit_hint = std::max<uint64_t>(J->seg_hit_hint, n_seg_hits);
+    unsigned long long n_out = 0;
+    if (seg->hook_final) {
+        n_out = seg->fan_count; // counted by the fan-out that ran behind the scan, read back with the scan's counters
+    } else {
+        unsigned long long *d_count = J->d_fan_count;
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+        if (n_seg_hits) {
+            jst_fan_params G = F;
+            G.hits = static_cast<const spm_hit *>(d_rec);
+            G.n_hits = n_seg_hits;
+            G.n_hits_dev = nullptr;
+            G.out_count = d_count;
+            hipLaunchKernelGGL(jst_fanout_kernel, dim3((unsigned)((n_seg_hits + 255) / 256)), dim3(256), 0, ctx->stream,
+                               J->dev(), G);
+            SPM_HIP_CHECK(ctx, hipGetLastError());
         }
-    if (!R->d)
-        SPM_HIP_CHECK(ctx, hipMalloc(&R->d, out_cap * sizeof(spm_jst_hit)));
-    R->cap = out_cap;
-    if (!J->d_fan_count) {
-        SPM_HIP_CHECK(ctx, hipMalloc(&J->d_fan_count, 8));
-        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[0]));
-        SPM_HIP_CHECK(ctx, hipEventCreate(&J->fan_ev[1]));
+        SPM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters + 8, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        n_out = ctx->h_counters[8];
     }
-    unsigned long long *d_count = J->d_fan_count;
-    SPM_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream));
-    hipEvent_t e0 = J->fan_ev[0], e1 = J->fan_ev[1];
-    SPM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
-    if (n_seg_hits) {
-        jst_fan_params F{};
-        F.hits = static_cast<const spm_hit *>(d_rec);
-        F.n_hits = n_seg_hits;
-        F.ctx_off = J->d_ctx_off;
-        F.n_ctx = J->n_ctx;
-        F.ctx_block = J->d_ctx_block;
-        F.ctx_owned = J->d_ctx_owned;
-        F.ctx_base = J->d_ctx_base;
-        F.local_id = J->d_local_id;
-        F.m = patterns->d_m;
-        F.report_begin = patterns->is_myers() ? 0 : 1;
-        F.out = R->d;
-        F.out_count = d_count;
-        F.out_cap = out_cap;
-        hipLaunchKernelGGL(jst_fanout_kernel, dim3((unsigned)((n_seg_hits + 255) / 256)), dim3(256), 0, ctx->stream,
-                           J->dev(), F);
-        SPM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    SPM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
-    SPM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters + 8, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long n_out = ctx->h_counters[8];
     hipEventElapsedTime(&J->stats.ms_fanout, e0, e1);
     if (n_out > out_cap) {
         SPM_SET_ERR(ctx, "journaled-sequence search produced %llu hits but the buffer holds %llu; raise "

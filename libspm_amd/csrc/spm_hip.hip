@@ -2016,10 +2016,12 @@ int run_filter(const scan_args &A)
 
 } // namespace
 
+// after_launch: work the caller wants on the stream right behind the filter scan's kernels, before the host reads the
+// counters (the pan-genome search's fan-out); spm_hits::hook_final tells whether it saw the final hit list.
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
                      uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets = nullptr,
-                     const uint32_t *d_seg_owned = nullptr);
+                     const uint32_t *d_seg_owned = nullptr, const std::function<int(spm_hits *)> *after_launch = nullptr);
 
 extern "C" int spm_hip_scan(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end,
                             const spm_patterns *patterns, const spm_scan_opts *opts_in, const void *state_in,
@@ -2051,7 +2053,8 @@ extern "C" int spm_hip_scan_segments(spm_ctx *ctx, const spm_text *text, const u
 
 static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, const spm_patterns *patterns,
                      const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
-                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets, const uint32_t *d_seg_owned)
+                     uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets, const uint32_t *d_seg_owned,
+                     const std::function<int(spm_hits *)> *after_launch)
 {
     if (!ctx || !text || !patterns || !out || begin > end || end > text->n) {
         SPM_SET_ERR(ctx, "spm_hip_scan: invalid argument");
@@ -2152,8 +2155,13 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
+            if (after_launch && !stateful) {
+                rc = (*after_launch)(H.get());
+                if (rc != SPM_OK)
+                    return rc;
+            }
             // the overflow checks need the counters: one small D2H copy
-            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, H->d_count, 13 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             if (c[2] == 0)
                 ctx->band_dirty = false; // every band was consumed: the table is empty again
@@ -2271,6 +2279,10 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
         } else {
             H->n = c[0];
             H->counted = true;
+            if (after_launch && !stateful) { // nothing was added to the hit list after the caller's work ran on it
+                H->hook_final = true;
+                H->fan_count = c[12];
+            }
         }
         if (!again)
             break;
