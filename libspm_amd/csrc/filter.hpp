@@ -1986,14 +1986,21 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         // shorter band shares the wave).  The steps in between -- nearly all -- run without exec-mask changes and with
         // the match mask picked by bit selects instead of compare / cndmask chains: a band is a serial chain of ~1400
         // steps, one wave per SIMD, so the scan pays for every instruction and every VALU -> SALU hand-over of a step.
+        // (unchecked steps: a lane that holds a block reads its own column, any other lane anything inside its group's LDS;
+        // only the lane of the last block can meet score <= k_hit)
+        const uint8_t *my_text = mine ? tw + skew - gl : tw;
+        const int32_t k_hit = (is_last && mine) ? (int32_t)k : -1;
+        const uint32_t n_rel = n_cols - first_slot_col; // end-position slots of this band
         auto step = [&](uint32_t t, auto checked, auto dna4) {
             const uint32_t ho_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ho, 0x138, 0xF, 0xF, false);
             const uint32_t col = t - gl; // wraps for t < gl: then col >= n_cols
             const uint32_t sym = sym_next;
-            {   // next column's symbol, one step ahead of its use
+            if constexpr (decltype(checked)::value) { // next column's symbol, one step ahead of its use
                 uint32_t nc = col + 1;
                 nc = nc < n_cols ? nc : 0u;
                 sym_next = tw[skew + nc];
+            } else {
+                sym_next = my_text[t + 1];
             }
             if (!decltype(checked)::value || (mine && col < n_cols)) {
                 uint32_t Eq;
@@ -2022,8 +2029,9 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 score += (int32_t)op - (int32_t)on;
-                if (is_last && mine && score <= (int32_t)k && col >= first_slot_col && col < n_cols) {
-                    hb[col - first_slot_col] = (uint16_t)(score + 1);
+                const uint32_t rel = col - first_slot_col;
+                if (score <= k_hit && rel < n_rel) {
+                    hb[rel] = (uint16_t)(score + 1);
                     any_hit = true;
                 }
             }
