@@ -1943,13 +1943,16 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         const bool mine = active && gl < nb;
         // ---- stage the text window [ws, e_hi) into LDS: 16-byte blocks, the group's lanes side by side ----
         const uint32_t skew = (uint32_t)(ws & 15);
+        uint32_t beyond4 = 0; // a byte >= 4 somewhere in the window (never in a validated dna4 text)
         if (active) {
             const uint32_t n_bytes = (skew + n_cols + 15) & ~15u;
             for (uint32_t off = gl * 16; off < n_bytes; off += G * 16) {
                 const uint4 v = load_text16(P.text, ((uint64_t)ws & ~15ull) + off, P.text_alloc);
                 *reinterpret_cast<uint4 *>(tw + off) = v;
+                beyond4 |= (v.x | v.y | v.z | v.w) & 0xFCFCFCFCu;
             }
         }
+        const bool plain4 = P.sigma == 4 && __ballot(beyond4 != 0) == 0; // (wave-uniform) every symbol selects a match mask
         uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
         if (mine) {
             const uint32_t *src = peq_bot + (((size_t)(pat >> 6) * rows) * P.nw_table + gl) * 64 + (pat & 63);
@@ -1971,16 +1974,22 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         uint32_t t_wave = active ? t_end : 0u;
         // ... and the steps in which EVERY block of every band of the wave has a column of its window: [t_lo, t_hi)
         uint32_t t_lo = active ? nb - 1 : 0u, t_hi = active ? n_cols : 0xFFFFFFFFu;
+        // ... and the first step at which a band of the wave can report an end position (its last block reaches the column
+        // of e_lo): the steps before it -- three in four for |P| = 1024, k = 64 -- do not look for hits at all
+        uint32_t t_hit = active ? first_slot_col + nb - 1 : 0xFFFFFFFFu;
         for (int o = 32; o >= (int)G; o >>= 1) {
             t_wave = max(t_wave, (uint32_t)__shfl_xor((int)t_wave, o));
             t_lo = max(t_lo, (uint32_t)__shfl_xor((int)t_lo, o));
             t_hi = min(t_hi, (uint32_t)__shfl_xor((int)t_hi, o));
+            t_hit = min(t_hit, (uint32_t)__shfl_xor((int)t_hit, o));
         }
         t_wave = (uint32_t)__builtin_amdgcn_readfirstlane(t_wave);
         t_lo = (uint32_t)__builtin_amdgcn_readfirstlane(t_lo);
         t_hi = (uint32_t)__builtin_amdgcn_readfirstlane(t_hi);
+        t_hit = (uint32_t)__builtin_amdgcn_readfirstlane(t_hit);
         t_hi = t_hi > t_wave ? t_wave : t_hi;
         t_lo = t_lo > t_hi ? t_hi : t_lo;
+        t_hit = t_hit < t_lo ? t_lo : (t_hit > t_hi ? t_hi : t_hit);
         uint32_t sym_next = mine ? tw[skew] : 0u; // column 0 (clamped reads below keep every index inside the window)
         // One step of one block.  CHECKED: the lane may have no column at this step (the pipeline fills and drains, or a
         // shorter band shares the wave).  The steps in between -- nearly all -- run without exec-mask changes and with
@@ -1991,7 +2000,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         const uint8_t *my_text = mine ? tw + skew - gl : tw;
         const int32_t k_hit = (is_last && mine) ? (int32_t)k : -1;
         const uint32_t n_rel = n_cols - first_slot_col; // end-position slots of this band
-        auto step = [&](uint32_t t, auto checked, auto dna4) {
+        auto step = [&](uint32_t t, auto checked, auto dna4, auto hits) {
             const uint32_t ho_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ho, 0x138, 0xF, 0xF, false);
             const uint32_t col = t - gl; // wraps for t < gl: then col >= n_cols
             const uint32_t sym = sym_next;
@@ -2007,8 +2016,7 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 if constexpr (decltype(dna4)::value) {
                     const uint32_t s0 = (uint32_t)((int32_t)(sym << 31) >> 31), s1 = (uint32_t)((int32_t)(sym << 30) >> 31);
                     const uint32_t lo2 = (e1 & s0) | (e0 & ~s0), hi2 = (e3 & s0) | (e2 & ~s0);
-                    Eq = (hi2 & s1) | (lo2 & ~s1);
-                    Eq = sym < 4 ? Eq : 0u;
+                    Eq = (hi2 & s1) | (lo2 & ~s1); // (plain4: no symbol beyond 3 in the window)
                 } else {
                     const uint32_t lo2 = (sym & 1u) ? e1 : e0, hi2 = (sym & 1u) ? e3 : e2;
                     Eq = (sym & 2u) ? hi2 : lo2;
@@ -2029,24 +2037,29 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 score += (int32_t)op - (int32_t)on;
-                const uint32_t rel = col - first_slot_col;
-                if (score <= k_hit && rel < n_rel) {
-                    hb[rel] = (uint16_t)(score + 1);
-                    any_hit = true;
+                if constexpr (decltype(hits)::value) {
+                    const uint32_t rel = col - first_slot_col;
+                    if (score <= k_hit && rel < n_rel) {
+                        hb[rel] = (uint16_t)(score + 1);
+                        any_hit = true;
+                    }
                 }
             }
         };
         uint32_t t = 0;
         for (; t < t_lo; ++t)
-            step(t, std::true_type{}, std::false_type{});
-        if (P.sigma == 4)
+            step(t, std::true_type{}, std::false_type{}, std::true_type{});
+        if (plain4) {
+            for (; t < t_hit; ++t)
+                step(t, std::false_type{}, std::true_type{}, std::false_type{});
             for (; t < t_hi; ++t)
-                step(t, std::false_type{}, std::true_type{});
-        else
+                step(t, std::false_type{}, std::true_type{}, std::true_type{});
+        } else {
             for (; t < t_hi; ++t)
-                step(t, std::false_type{}, std::false_type{});
+                step(t, std::false_type{}, std::false_type{}, std::true_type{});
+        }
         for (; t < t_wave; ++t)
-            step(t, std::true_type{}, std::false_type{});
+            step(t, std::true_type{}, std::false_type{}, std::true_type{});
         // ---- emission: the lanes of a group share its slots; wave-converged appends ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
