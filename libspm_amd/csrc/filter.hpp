@@ -17,17 +17,19 @@
 //   Level 1 (filter kernel, the streaming kernel): each lane loads 16 text bytes (one 16-byte coalesced load),
 //   packs them to 2 bits/base with 4 v_dot4_u32_u8, takes the previous lane's word through DPP wave_shr:1, forms
 //   the 16/S windows with v_alignbit and looks them up in a perfect-hash fingerprint table held in LDS (two LDS
-//   reads per window; a Bloom cascade is kept as fallback).  Survivors are looked up in an exact key table in L2
-//   and emitted as candidates (text position, needle, needle offset).
-//   Level 2 (verification): the Myers recurrence over the m+3k symbols around the candidate diagonal, cold-started
+//   reads per window; a Bloom cascade is kept as fallback) and records the windows that pass (survivors).  Needle
+//   sets of several stride-1 passes use anchored keys: a pass looks up only the windows that begin with its dimer.
+//   Resolve (resolve_kernel): survivors -> the key's entries through an exact key directory in L2 -> whole-seed and
+//   piece-count checks -> diagonal bands.
+//   Verification: the Myers recurrence over the m+3k symbols around the candidate diagonal, cold-started
 //   m+k symbols before the first end position it is responsible for -- exact by the window property used for
 //   tiling.  Short needles: one lane per candidate (verify_kernel); long needles: one lane per 32-row block
 //   (verify_wave_kernel).  Duplicates (several seeds of one occurrence) are removed with an atomicCAS hash set keyed
 //   by (needle, end).
 //
 // Exactness does not depend on the text being random: every true hit has a surviving seed, every candidate is
-// verified by the full recurrence.  Pathological inputs only cost time; if the candidate buffer overflows the
-// host re-runs the scan with the brute-force engine.
+// verified by the full recurrence.  Pathological inputs only cost time: a span of the text that yields more survivors
+// than its budget is scanned again by the brute-force kernel, that span alone.
 #pragma once
 
 #include "brute.hpp"
@@ -58,7 +60,6 @@ __host__ __device__ inline seed_plan plan_seeds(uint32_t m, uint32_t k)
     const uint32_t surplus = (k >= kMergeMinK && k <= 1000 && m / (k + 2) >= kKeyMin) ? 2u : 1u;
     return {k + surplus, m / (k + surplus)};
 }
-constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
 
 // What the streaming kernel leaves behind: one record per text window whose key passed level 1 (practically: a real
 // seed key).  The exact key table in L2 is NOT consulted while streaming -- an L2 round trip per survivor stalls a wave
@@ -941,7 +942,7 @@ struct verify_params
 };
 
 // ---------------------------------------------------------------------------------------------------
-// resolve: survivors -> (needle, offset) through the exact key table -> whole-seed check -> diagonal bands
+// resolve: survivors -> (needle, offset) through the exact key directory -> whole-seed check, piece count -> diagonal bands
 // ---------------------------------------------------------------------------------------------------
 // One lane per survivor, a full grid: the L2 round trips of the table probes overlap across thousands of waves instead of
 // stalling the streaming kernel.
