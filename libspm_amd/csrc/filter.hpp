@@ -1817,25 +1817,29 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         uint4 nxt = make_uint4(0, 0, 0, 0);
         if (active)
             nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
-        for (int64_t blk = blk0; blk < e_hi; blk += 16) {
+        // columns in 32-bit terms relative to the cold start: rel = p - ws in [0, n_cols); end position slot = rel - rel_lo
+        const uint32_t n_cols = (uint32_t)(e_hi - ws);
+        const uint32_t rel_lo = (uint32_t)(e_lo - 1 - ws);
+        const uint32_t sigma = P.sigma;
+        uint32_t rel0 = (uint32_t)(blk0 - ws); // (wraps below zero for the symbols of the first block before ws)
+        for (int64_t blk = blk0; blk < e_hi; blk += 16, rel0 += 16) {
             const uint4 cur = nxt;
             if (blk + 16 < e_hi)
                 nxt = load_text16(P.text, (uint64_t)(blk + 16), P.text_alloc);
             const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int64_t p = blk + i;
-                if (p < ws || p >= e_hi)
+                const uint32_t rel = rel0 + (uint32_t)i;
+                if (rel >= n_cols)
                     continue;
                 uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 0xFF;
-                sym = sym < P.sigma ? sym : P.sigma;
+                sym = sym < sigma ? sym : sigma;
                 L.step_strided(vlds + ((size_t)sym * NWN) * nthr + tid, nthr);
-                const int64_t e = p + 1;
-                if (L.score <= (int32_t)k && e >= e_lo) {
+                if (L.score <= (int32_t)k && rel >= rel_lo) {
                     // remember the hit; emission is deferred until the whole wave has finished scanning so that the
                     // CAS / append atomics (1-2 us each) are issued once per end-position slot for all lanes together
                     // instead of stalling the wave at ~every lane's own hit
-                    hitbuf[(size_t)(e - e_lo) * nthr + tid] = (uint16_t)(L.score + 1);
+                    hitbuf[(size_t)(rel - rel_lo) * nthr + tid] = (uint16_t)(L.score + 1);
                     any_hit = true;
                 }
             }
