@@ -1948,8 +1948,13 @@ int run_filter(const scan_args &A)
     // grid: what earlier scans of this needle set produced (a full grid of idle workgroups costs ~30 us on a 2.6 ms scan);
     // a scan that produces more simply loops
     const uint64_t surv_expect = ps->cand_hint ? 2 * ps->cand_hint : surv_cap;
-    const uint64_t rmax = (uint64_t)ctx->n_cu * (uint64_t)std::max(1, env_int("SPM_HIP_RESOLVE_WGS_PER_CU", 8));
-    const uint32_t rgrid = (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(ctx->n_cu / 2, (surv_expect + 255) / 256));
+    // (5 workgroups per CU are resident at once -- LDS queues, 84 VGPRs --: a larger grid only adds a second, partly filled
+    // round.  A lane takes ~4 survivors in turn: measured on C5, whose survivors are few and cheap, 0.137 -> 0.10 ms;
+    // c3r 1.33 -> 1.25 ms with the cap alone.)
+    const uint64_t rmax = (uint64_t)ctx->n_cu * (uint64_t)std::max(1, env_int("SPM_HIP_RESOLVE_WGS_PER_CU", 5));
+    // (a short survivor list: one survivor per lane, its latency is the kernel's; a long one: four per lane)
+    const uint64_t per_wg = (surv_expect + 255) / 256 <= rmax ? 256 : (uint64_t)std::max(256, env_int("SPM_HIP_RESOLVE_SURV_PER_WG", 1024));
+    const uint32_t rgrid = (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(ctx->n_cu / 2, (surv_expect + per_wg - 1) / per_wg));
     hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, R);
     SPM_HIP_CHECK(ctx, hipGetLastError());
 
