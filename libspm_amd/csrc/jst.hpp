@@ -464,6 +464,22 @@ struct jst_fan_params
     uint64_t out_cap;
 };
 
+// the context ids of 8 consecutive haplotypes of one block: one 16-byte load when the row allows it
+__device__ __forceinline__ void jst_load_ids8(const uint16_t *p, uint32_t n_valid, uint16_t (&v)[8])
+{
+    if (n_valid >= 8 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = (uint32_t)i < n_valid ? p[i] : kJstNone;
+    }
+}
+
 // One thread per segment hit: drop it if its last symbol lies in the left context, else report it for every haplotype
 // of the context's group, in haplotype coordinates.  Output slots are drawn with one atomic per wave (a per-record
 // atomic on the single counter cost 0.6 ms for 10^6 records).
@@ -506,9 +522,12 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
         h_lo = (uint32_t)(cb % J.n_groups) * kJstGroup;
         h_hi = min(J.n_hap, h_lo + kJstGroup);
         id = (uint32_t)(c - F.ctx_base[cb]);
-        for (uint32_t h = h_lo; h < h_hi; ++h) {
-            const uint16_t v = F.local_id[jr * J.n_hap + h];
-            members += (v != kJstNone && (uint32_t)(v & 0x7FFFu) == id) ? 1u : 0u;
+        for (uint32_t h = h_lo; h < h_hi; h += 8) {
+            uint16_t v[8];
+            jst_load_ids8(F.local_id + jr * J.n_hap + h, h_hi - h, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                members += (v[i] != kJstNone && (uint32_t)(v[i] & 0x7FFFu) == id) ? 1u : 0u;
         }
     }
     // one atomic per wave: exclusive prefix of the member counts over the lanes
@@ -528,22 +547,34 @@ __global__ void jst_fanout_kernel(jst_dev J, jst_fan_params F)
     // pass 2: report the hit for every haplotype of the group, in haplotype coordinates
     unsigned long long slot = base + (incl - members);
     const uint64_t j = J.jb + jr;
-    for (uint32_t h = h_lo; h < h_hi; ++h) {
-        const uint16_t v = F.local_id[jr * J.n_hap + h];
-        if (v == kJstNone || (uint32_t)(v & 0x7FFFu) != id)
-            continue;
-        const uint64_t a = J.hap_start[j * J.n_hap + h];
-        const uint64_t ctx_lo = a - std::min<uint64_t>(J.window ? J.window - 1 : 0, a);
-        if (slot < F.out_cap) {
-            spm_jst_hit o;
-            o.pos = ctx_lo + local;
-            o.haplotype = h;
-            o.pattern = hit.pattern;
-            o.score = hit.score;
-            o.reserved = 0;
-            F.out[slot] = o;
+    // (eight haplotypes at a time: their start coordinates are loaded together, then the records are stored -- one at a
+    // time the compiler has to keep every load behind the previous record's store, a dependent round trip per member)
+    for (uint32_t h = h_lo; h < h_hi; h += 8) {
+        uint16_t v[8];
+        jst_load_ids8(F.local_id + jr * J.n_hap + h, h_hi - h, v);
+        bool mem[8];
+        uint64_t a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mem[i] = v[i] != kJstNone && (uint32_t)(v[i] & 0x7FFFu) == id;
+            a[i] = mem[i] ? J.hap_start[j * J.n_hap + h + i] : 0;
         }
-        ++slot;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!mem[i])
+                continue;
+            const uint64_t ctx_lo = a[i] - std::min<uint64_t>(J.window ? J.window - 1 : 0, a[i]);
+            if (slot < F.out_cap) {
+                spm_jst_hit o;
+                o.pos = ctx_lo + local;
+                o.haplotype = h + i;
+                o.pattern = hit.pattern;
+                o.score = hit.score;
+                o.reserved = 0;
+                F.out[slot] = o;
+            }
+            ++slot;
+        }
     }
     }
 }
