@@ -113,7 +113,7 @@ __device__ __forceinline__ void brute_report(const brute_params &P, bool hit, ui
             const unsigned long long key = ((unsigned long long)pattern << 40) | (unsigned long long)e;
             uint32_t slot = (uint32_t)seen_hash(key) & P.seen_mask;
             bool placed = false, fresh = false;
-            for (uint32_t tries = 0; tries < 512 && !placed; ++tries) {
+            for (uint32_t tries = 0; tries < 64 && !placed; ++tries) { // (as seen_insert, filter.hpp)
                 const unsigned long long old = atomicCAS(&P.seen[slot], ~0ull, key);
                 if (old == ~0ull) {
                     fresh = true;

@@ -1334,7 +1334,7 @@ __device__ __forceinline__ bool seen_insert_raw(unsigned long long *seen, uint32
     uint32_t slot = (uint32_t)(mix64(key)) & seen_mask;
     // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means more hits than
     // it was sized for: flag it, the host starts over with a larger one
-    for (uint32_t tries = 0; tries < 512; ++tries) {
+    for (uint32_t tries = 0; tries < 64; ++tries) {
         const unsigned long long old = atomicCAS(&seen[slot], ~0ull, key);
         if (old == ~0ull)
             return true;
