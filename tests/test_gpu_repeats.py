@@ -134,3 +134,42 @@ def test_hit_overflow_is_reported_not_rescanned(spm, ctx, oracle):
         h.view()
     h2 = spm.scan(ctx, text, ps, engine=spm.ENGINE_AUTO, max_hits=1 << 21)
     assert len(h2.view()) == n - 100 + 3 + 1
+
+
+@pytest.mark.parametrize("algo", ["shiftor", "horspool"])
+def test_exact_sets_with_and_without_repeat_needles(spm, ctx, oracle, algo):
+    """Exact sets (k = 0, every needle its own single seed): the resolve kernel reports the hits itself -- unless a needle
+    IS a repeat (its index entries are merged into a diagonal range and skip the whole-seed check), then the set goes
+    through bands and verification.  Either way: == the brute-force engine == the naive definition."""
+    rng = np.random.default_rng(17)
+    n = 1 << 22
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    T[1000:1400] = 0                                               # poly-A
+    T[9000:9600] = np.resize(np.array([0, 1], np.uint8), 600)      # (AC)n
+    L = 32
+    plain = [T[o:o + L].copy() for o in rng.integers(20000, n - L, 300)]
+    repeats = [np.zeros(L, np.uint8), np.resize(np.array([0, 1], np.uint8), L), np.resize(np.array([1, 0], np.uint8), L)]
+    a = spm.ALGO_SHIFTOR if algo == "shiftor" else spm.ALGO_HORSPOOL
+    text = ctx.upload(T)
+    for needles, with_runs in ((plain, False), (plain + repeats, True)):
+        ps = ctx.patterns(a, needles, k=0)
+        assert ps.filterable
+        hf = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 20)
+        st = hf.stats()
+        assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0
+        assert (st.n_bands > 0) == with_runs          # no bands at all when the resolve kernel reports the hits
+        got = hf.view()
+        want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 20).view()
+        assert np.array_equal(got, want) and len(want) >= 300
+        # the naive definition for a few needles (exact matchers report the begin position)
+        for p in (0, 7, len(needles) - 1):
+            nd = needles[p]
+            win = np.lib.stride_tricks.sliding_window_view(T, L)
+            begins = np.flatnonzero((win == nd).all(axis=1))
+            mine = np.sort(want["pos"][want["pattern"] == p])
+            assert np.array_equal(mine, begins.astype(np.uint64))
+        # a sub-range with left context and an offset: ownership by the last symbol, reported by the resolve kernel too
+        lo, hi = 500, 12000
+        h1 = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=True, pos_offset=77).view()
+        h2 = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=True, pos_offset=77).view()
+        assert np.array_equal(h1, h2)
