@@ -510,7 +510,6 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         max_hits = 1 << 26
         cap = max_hits
     hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
-    count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
     # few records (C2, C3: <= 128 KB per rank): one fused all-gather of fixed-size buffers, no count exchange;
     # many (C4: ~51 000 hits per rank, c3r: millions): the count-then-send gatherv moves what there is, not the capacity
     fused = cap <= (1 << 13)
@@ -518,12 +517,11 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     def step():
         h = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
                    pos_offset=lo - ovl, max_hits=max_hits)
-        n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
         if fused:
-            count_host[0] = n
-            hit_buf[0].copy_(count_host, non_blocking=True)  # count
+            n = h.copy_fused(hit_buf.data_ptr(), cap)        # [count | records], on the scan's stream
             gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
         else:
+            n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
             gathered = sdist.gatherv_hits(hit_buf[1:1 + min(n, cap)])
         return h, gathered
 

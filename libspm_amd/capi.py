@@ -136,6 +136,7 @@ def lib():
         "spm_hip_hits_view": (C.c_int, [vp, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_uint64)]),
         "spm_hip_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "spm_hip_hits_copy_device": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "spm_hip_hits_copy_fused": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         "spm_hip_hits_stats": (C.c_int, [vp, C.POINTER(ScanStats)]),
         "spm_hip_hits_checksum": (C.c_uint64, [vp]),
         "spm_hip_hits_destroy": (None, [vp]),
@@ -185,7 +186,7 @@ EXPORTS = [
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
-    "spm_hip_hits_copy_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
+    "spm_hip_hits_copy_device", "spm_hip_hits_copy_fused", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
     "spm_hip_synth_repeat_pattern", "spm_hip_synth_repeat_text", "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
     "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",

@@ -2458,6 +2458,24 @@ extern "C" int spm_hip_hits_copy_device(spm_hits *h, void *device_dst, uint64_t 
     return SPM_OK;
 }
 
+extern "C" int spm_hip_hits_copy_fused(spm_hits *h, void *device_dst, uint64_t cap, uint64_t *n)
+{
+    if (!h || !n || !device_dst)
+        return SPM_E_INVALID;
+    int rc = hits_count(h);
+    if (rc != SPM_OK)
+        return rc;
+    *n = h->n;
+    // header: the count (16 bytes from pageable memory: staged by the runtime before the call returns)
+    const unsigned long long hdr[2] = {h->n, 0};
+    SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(device_dst, hdr, 16, hipMemcpyHostToDevice, h->ctx->stream));
+    const uint64_t c = std::min(h->n, cap);
+    if (c)
+        SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(static_cast<uint8_t *>(device_dst) + sizeof(spm_hit), h->d_hits, c * sizeof(spm_hit),
+                                             hipMemcpyDeviceToDevice, h->ctx->stream));
+    return SPM_OK;
+}
+
 extern "C" int spm_hip_hits_stats(const spm_hits *hc, spm_scan_stats *out)
 {
     if (!hc || !out)

@@ -188,6 +188,12 @@ class Hits:
         _check(capi.lib().spm_hip_hits_copy_device(self._h, C.c_void_p(device_ptr), cap, C.byref(n)), self.ctx._h)
         return int(n.value)
 
+    def copy_fused(self, device_ptr: int, cap: int) -> int:
+        """copy_to with a 16-byte {count, 0} header in front: the [count | records] buffer of dist.gather_hits_fused."""
+        n = C.c_uint64()
+        _check(capi.lib().spm_hip_hits_copy_fused(self._h, C.c_void_p(device_ptr), cap, C.byref(n)), self.ctx._h)
+        return int(n.value)
+
     def stats(self) -> capi.ScanStats:
         s = capi.ScanStats()
         _check(capi.lib().spm_hip_hits_stats(self._h, C.byref(s)), self.ctx._h)

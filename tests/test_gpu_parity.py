@@ -913,3 +913,33 @@ def test_native_rccl_gatherv_world_of_one(spm, ctx, oracle):
         assert L.spm_hip_gatherv_hits(comm, h._h, 3, C.byref(rec), C.byref(tot), counts) == -1   # no such root
     finally:
         L.spm_hip_comm_destroy(comm)
+
+
+def test_hits_copy_fused_and_copy_to(spm, ctx, oracle):
+    """spm_hip_hits_copy_device / _copy_fused: the records (and the [count | records] layout the fused all-gather ships)
+    land in a caller-owned device buffer, truncated to its capacity, the count always the true one."""
+    import torch
+    rng = np.random.default_rng(5)
+    T = rng.integers(0, 4, 1 << 20, dtype=np.uint8)
+    needles = [T[o:o + 64].copy() for o in rng.integers(0, (1 << 20) - 64, 200)]
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=1)
+    h = spm.scan(ctx, text, ps)
+    want = h.view()
+    n_true = len(want)
+    assert n_true >= 600                                   # every needle: its end position and the two next to it
+    key = lambda a: np.sort(a.view(np.uint8).reshape(-1, 16), axis=0).tobytes()  # (arrival order is not defined)
+    for cap in (n_true + 10, 50):
+        buf = torch.full((cap + 1, 2), -1, dtype=torch.int64, device="cuda")
+        n = h.copy_fused(buf.data_ptr(), cap)
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        assert n == n_true and host[0, 0] == n_true and host[0, 1] == 0
+        got = host[1:1 + min(n, cap)].copy().view(np.uint8).reshape(-1, 16)
+        if cap >= n_true:
+            assert key(got) == key(want.view(np.uint8).reshape(-1, 16))
+            assert (host[1 + n_true:] == -1).all()         # nothing written past the records
+        buf2 = torch.full((cap, 2), -1, dtype=torch.int64, device="cuda")
+        assert h.copy_to(buf2.data_ptr(), cap) == n_true
+        torch.cuda.synchronize()
+        assert np.array_equal(buf2.cpu().numpy()[:min(n, cap)], host[1:1 + min(n, cap)])
