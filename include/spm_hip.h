@@ -149,6 +149,23 @@ uint64_t spm_hip_patterns_window_size(const spm_patterns *p, uint32_t pattern);
 /* 1 if the set admits the lossless seed filter (dna4, every needle long enough for its k). */
 int spm_hip_patterns_filterable(const spm_patterns *p);
 
+/* What spm_hip_patterns_create spent where (host wall clock, ms) and what it built.  The reference's constructors are
+ * O(|P|) per needle (myers_matcher.hpp:40-43); a set of 100 000 needles is built by `threads` host threads here
+ * (SPM_HIP_BUILD_THREADS; default: the hardware concurrency, at most 16). */
+typedef struct spm_build_stats {
+    float ms_total;
+    float ms_tables;  /* match-mask tables of the bit-vector engines */
+    float ms_index;   /* seed index of the filter engine */
+    float ms_upload;  /* device allocations + host-to-device copies */
+    uint32_t threads;
+    uint32_t passes;            /* passes of the seed filter over the text per scan (0: brute-force engine only) */
+    uint32_t dense;             /* 1: the one dense pass (presence bits in LDS + fingerprint buckets in L2) */
+    uint32_t anchor_sixteenths; /* sixteenths of all text windows that are looked up, summed over the passes */
+    uint64_t keys;              /* indexed windows */
+    uint32_t stride, key_len;
+} spm_build_stats;
+int spm_hip_patterns_build_stats(const spm_patterns *p, spm_build_stats *out);
+
 /* ---- matcher state: replaces capture()/restore() (myers_matcher_restorable.hpp:57-63,136-142;
  * shiftor_matcher_restorable.hpp:44-50).  A state blob holds one record per pattern, each
  * spm_hip_patterns_state_stride() bytes:

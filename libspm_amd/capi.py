@@ -54,6 +54,22 @@ class ScanStats(C.Structure):
     ]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_float),
+        ("ms_tables", C.c_float),
+        ("ms_index", C.c_float),
+        ("ms_upload", C.c_float),
+        ("threads", C.c_uint32),
+        ("passes", C.c_uint32),
+        ("dense", C.c_uint32),
+        ("anchor_sixteenths", C.c_uint32),
+        ("keys", C.c_uint64),
+        ("stride", C.c_uint32),
+        ("key_len", C.c_uint32),
+    ]
+
+
 class JstAllele(C.Structure):
     _fields_ = [("pos", C.c_uint64), ("ref_len", C.c_uint32), ("alt_len", C.c_uint32), ("alt_off", C.c_uint64)]
 
@@ -88,7 +104,7 @@ class JstStats(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libspm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     srcs.append(os.path.join(_PKG, "..", "include", "spm_hip.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -128,6 +144,7 @@ def lib():
         "spm_hip_patterns_destroy": (None, [vp]),
         "spm_hip_patterns_window_size": (C.c_uint64, [vp, C.c_uint32]),
         "spm_hip_patterns_filterable": (C.c_int, [vp]),
+        "spm_hip_patterns_build_stats": (C.c_int, [vp, C.POINTER(BuildStats)]),
         "spm_hip_patterns_state_stride": (C.c_size_t, [vp]),
         "spm_hip_patterns_state_init": (C.c_int, [vp, vp]),
         "spm_hip_scan": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, C.POINTER(ScanOpts), vp, vp, C.POINTER(vp)]),
@@ -184,7 +201,7 @@ EXPORTS = [
     "spm_hip_text_wrap", "spm_hip_text_generate", "spm_hip_text_generate_repeats", "spm_hip_text_pack", "spm_hip_text_is_packed",
     "spm_hip_text_download", "spm_hip_text_length",
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
-    "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_state_stride",
+    "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_build_stats", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
     "spm_hip_hits_copy_device", "spm_hip_hits_copy_fused", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
     "spm_hip_synth_repeat_pattern", "spm_hip_synth_repeat_text", "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",

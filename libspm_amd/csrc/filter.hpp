@@ -34,32 +34,11 @@
 
 #include "brute.hpp"
 #include "common.hpp"
+#include "filter_shared.hpp"
 #include "synth.hpp"
 
 namespace spm_hip
 {
-
-constexpr uint32_t kKeyMax = 16; // symbols per key: 16 whenever the seeds allow it, down to kKeyMin for short seeds
-// Short keys match by chance (windows x keys / 4^H survivors).  The streaming kernel only records a survivor (16 bytes)
-// and resolve_kernel disposes of it in ~0.2 ns of GPU time, so keys down to 9 symbols pay: |P| = 32, k = 2 (seeds of 10)
-// with 1000 needles leaves 0.3 % of the windows -- against a ~3000x slower brute-force scan.  A set whose keys would let
-// more than kMaxSurvivorShare of all windows through stays with the brute-force engine.
-constexpr uint32_t kKeyMin = 9;
-constexpr double kMaxSurvivorShare = 0.08;
-
-// Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
-// needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
-// hits per diagonal band and skip bands with a single one (candidate merging below).
-constexpr uint32_t kMergeMinK = 8;
-struct seed_plan
-{
-    uint32_t n, q;
-};
-__host__ __device__ inline seed_plan plan_seeds(uint32_t m, uint32_t k)
-{
-    const uint32_t surplus = (k >= kMergeMinK && k <= 1000 && m / (k + 2) >= kKeyMin) ? 2u : 1u;
-    return {k + surplus, m / (k + surplus)};
-}
 
 // What the streaming kernel leaves behind: one record per text window whose key passed level 1 (practically: a real
 // seed key).  The exact key table in L2 is NOT consulted while streaming -- an L2 round trip per survivor stalls a wave
@@ -135,69 +114,16 @@ struct filter_params
     uint32_t pass;            // which sub-batch of the needle set this launch filters for (survivor::pad)
     uint32_t anchor_c, anchor_cm; // anchored passes: a window is looked up iff its leading dimer d = sym0 | sym1 << 2 has
                                   // (d ^ anchor_c) & anchor_cm == 0
+    // dense passes (filter_shared.hpp): lds = presence bits; a window is looked up iff its dimer matches one of the n_pat patterns
+    uint32_t n_pat, pat_c[kDensePatterns], pat_cm[kDensePatterns];
+    uint32_t bucket_shift;
+    const uint4 *buckets;     // fingerprint buckets, L2-resident
     survivor *surv;
     unsigned long long *counters; // [1] = survivor slots drawn, [6] = spans that gave up, [2] = hard overflow
     uint64_t surv_cap;
     uint64_t *ovf_spans;      // [ovf_cap][2]: {first text index, symbols} of every span that gave up
     uint64_t ovf_cap;
 };
-
-template <int HV>
-__host__ __device__ inline uint32_t bloom_hash(uint32_t key, uint32_t i)
-{
-    // i-th probe index (before masking to the bitmap size).
-    if (HV != 1) {
-        // multiplicative hashing, distinct odd constants (v_mul_lo_u32 is quarter rate on CDNA)
-        const uint32_t c[4] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
-        uint32_t x = key ^ (key >> (15 + i));
-        return (x * c[i & 3]) >> 7;
-    } else {
-        // xor-shift + rotate: 3 full-rate VALU.  Index bits are GF(2)-linear in the key; on the text side the
-        // keys are (near) uniform 16-mers, so linearity costs nothing there.
-        const uint32_t sh[4] = {14, 11, 17, 9};
-        const uint32_t ro[4] = {0, 7, 13, 19};
-        const uint32_t x = key ^ (key >> sh[i & 3]);
-        return ro[i & 3] ? ((x >> ro[i & 3]) | (x << (32 - ro[i & 3]))) : x;
-    }
-}
-
-// ---- perfect-hash fingerprint table (hash-and-displace) ---------------------------------------------------------
-// The key set is static, so level 1 can be (almost) exact instead of probabilistic: every key k gets the slot
-//     slot(k) = (s1(k) + D[bucket(k)] * s2(k)) & slot_mask
-// where the displacement D[b] is chosen on the host, bucket by bucket, so that no two keys share a slot; the slot
-// holds a 16-bit fingerprint of its key.  A text window is a candidate iff the fingerprint at its slot matches:
-// two LDS reads, no cascade, false-positive rate = load * 2^-16 (< 1e-5), so the exact key table in L2 is
-// consulted practically only for real seed matches.
-struct chd_hashes
-{
-    uint32_t x;  // key * C: bucket = x >> shift, s1 = x >> 3
-    uint32_t s2; // per-key stride of the displacement (odd)
-    uint32_t f;  // 16-bit fingerprint
-};
-
-__host__ __device__ inline chd_hashes chd_hash(uint32_t key)
-{
-    chd_hashes h;
-    h.x = key * 0x9E3779B1u; // (two 24-bit multiplies instead of this quarter-rate one measured 8 % SLOWER on C4: the
-                             // weaker mixing costs more in LDS bank conflicts than the multiply saves)
-    h.s2 = (key | 1u) & 0xFFFFFFu;
-    h.f = (key ^ (key >> 16)) & 0xFFFFu;
-    return h;
-}
-
-__host__ __device__ inline uint32_t chd_slot(const chd_hashes &h, uint32_t d, uint32_t slot_mask)
-{
-    return ((h.x >> 3) + d * h.s2) & slot_mask;
-}
-
-__host__ __device__ inline uint32_t ht_hash(uint32_t key)
-{
-    uint32_t x = key ^ (key >> 16);
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    return x ^ (x >> 16);
-}
 
 // text bytes 16*lane .. 16*lane+15 of a chunk -> 32-bit word, base i at bits 2i..2i+1
 __device__ __forceinline__ uint32_t pack16(const uint4 v)
@@ -750,6 +676,242 @@ __global__ __launch_bounds__(((S == 1 && !KM && SIG == 4) || (S == 2 && U == 2))
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dense pass: every key of a needle set of any size in ONE pass over the text (filter_shared.hpp, index_build.hpp).
+//   level 0   which of a lane's 16 windows per word begin with an anchor dimer: bit-parallel on the packed word
+//             (dense_select: ~6 VALU per pattern and word); 1/8 .. 3/16 of the windows for the usual sets;
+//   level 1   one presence bit per key in LDS (2^20 bits), looked up for the anchored windows in a per-lane loop over the
+//             set bits of two words; about a third of them pass with 400 000 keys;
+//   level 1b  those wait in a per-wave LDS queue {key, offset in the span} until 64 or more are there; then the wave takes
+//             them one per lane, gathers each one's 16-byte fingerprint bucket from L2 (up to kDenseBatches batches in
+//             flight together: the chip serves ~2.7e11 such gathers per second, tools/l2_gather_probe.hip, so the queue
+//             exists to issue them 64 lanes wide and to keep several round trips overlapping), and compares the 15-bit
+//             fingerprint with the bucket's eight slots;
+//   what matches is a survivor like those of the sparse passes: recorded for resolve_kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kDenseQueueCap = 192; // entries per wave
+constexpr int kDenseBatches = 3;
+
+template <int NP>
+__device__ __forceinline__ uint32_t dense_select(const filter_params &P, uint32_t w, uint32_t prev)
+{
+    const uint32_t X = alignbit(w, prev, 2); // symbols 1..16: where the windows start
+    const uint32_t Y = alignbit(w, prev, 4); // symbols 2..17: their second symbols
+    uint32_t sel = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        // (wave-uniform) the pattern's bits for the first and the second symbol, repeated for every symbol of a word
+        const uint32_t C0 = (P.pat_c[i] & 3u) * 0x55555555u, M0 = (P.pat_cm[i] & 3u) * 0x55555555u;
+        const uint32_t C1 = (P.pat_c[i] >> 2) * 0x55555555u, M1 = (P.pat_cm[i] >> 2) * 0x55555555u;
+        uint32_t t = ((X ^ C0) & M0) | ((Y ^ C1) & M1); // a set bit: that bit of that symbol differs from the pattern
+        t |= t >> 1;
+        sel |= ~t;
+    }
+    return sel & 0x55555555u; // bit 2 (d - 1): window d (1..16) of this word begins with an anchor
+}
+
+struct dense_queue // per wave, in LDS behind the survivor-chunk records
+{
+    uint32_t key[kDenseQueueCap];
+    uint32_t off[kDenseQueueCap]; // window start - span begin + 16
+};
+
+// Take queued windows through level 1b: full batches of 64 (`all`: the rest too).  Wave-uniform call.
+__device__ __forceinline__ void dense_drain(const filter_params &P, dense_queue &Q, uint32_t &qn, bool all, uint64_t span_base,
+                                            uint32_t lane, const uint32_t *lds)
+{
+    while (qn >= 64 || (all && qn != 0)) {
+        const uint32_t nb_full = qn >> 6;
+        uint32_t nb = all ? (qn + 63) >> 6 : nb_full;
+        nb = nb > (uint32_t)kDenseBatches ? (uint32_t)kDenseBatches : nb;
+        uint32_t key[kDenseBatches], off[kDenseBatches];
+        uint4 bk[kDenseBatches];
+        bool v[kDenseBatches];
+#pragma unroll
+        for (int b = 0; b < kDenseBatches; ++b) { // entries [qn - 64 (b + 1), qn - 64 b), from the top of the queue
+            const int32_t e = (int32_t)qn - 64 * b - 1 - (int32_t)lane;
+            v[b] = (uint32_t)b < nb && e >= 0;
+            key[b] = 0;
+            off[b] = 0;
+            bk[b] = make_uint4(0, 0, 0, 0);
+            if (v[b]) {
+                key[b] = Q.key[e];
+                off[b] = Q.off[e];
+                bk[b] = P.buckets[dense_bucket(key[b], P.bucket_shift)];
+            }
+        }
+        qn = qn > 64 * nb ? qn - 64 * nb : 0;
+#pragma unroll
+        for (int b = 0; b < kDenseBatches; ++b) {
+            if ((uint32_t)b >= nb)
+                break; // (wave-uniform)
+            const uint32_t f2 = dense_fp(key[b]) * 0x00010001u;
+            // a 16-bit slot equal to the fingerprint <=> a zero halfword in slot ^ fingerprint
+            const uint32_t x0 = bk[b].x ^ f2, x1 = bk[b].y ^ f2, x2 = bk[b].z ^ f2, x3 = bk[b].w ^ f2;
+            const uint32_t z = ((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) |
+                               ((x3 - 0x00010001u) & ~x3);
+            const bool hit = v[b] && ((z & 0x80008000u) != 0 || (bk[b].w >> 16) == kDenseAcceptAll);
+            if (__ballot(hit) != 0) { // rare: a survivor for resolve_kernel
+                if (__builtin_amdgcn_readfirstlane(cand_chunk_of(P, lds)[5]) == 0) { // (unless the span has given up)
+                    const int64_t ts = (int64_t)span_base + (int64_t)off[b] - 16;
+                    const bool has = hit && ts >= (int64_t)P.lo && (uint64_t)ts + P.key_len <= P.hi;
+                    emit_survivors(P, has, key[b], has ? (uint64_t)ts : 0, lane, lds);
+                }
+            }
+        }
+    }
+}
+
+template <int UU, int NP>
+__device__ __forceinline__ void dense_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase, uint64_t span_base,
+                                            uint32_t &carry_in, uint32_t lane, const uint32_t *lds, dense_queue &Q, uint32_t &qn)
+{
+    static_assert(UU % 2 == 0 || UU == 1, "words are taken in pairs");
+    uint32_t w[UU], prev[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        w[u] = pack16(cur[u]);
+        prev[u] = __builtin_amdgcn_update_dpp(0u, w[u], 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+        if (lane == 0)
+            prev[u] = carry_in;
+        carry_in = __builtin_amdgcn_readlane(w[u], 63);
+    }
+    const uint32_t goff = (uint32_t)(gbase - span_base) + lane * 16; // (this lane's first base of chunk 0) - span begin
+#pragma unroll
+    for (int j = 0; j < UU; j += 2) {
+        constexpr bool pair = UU > 1;
+        // the anchored windows of two words in one mask: bit b = word j + (b & 1), window (b >> 1) + 1
+        uint32_t todo = dense_select<NP>(P, w[j], prev[j]);
+        if (pair)
+            todo |= dense_select<NP>(P, w[pair ? j + 1 : j], prev[pair ? j + 1 : j]) << 1;
+        while (__ballot(todo != 0) != 0) {
+            const bool act = todo != 0;
+            const uint32_t b = act ? (uint32_t)__ffs(todo) - 1u : 0u;
+            todo &= todo - 1;
+            const uint32_t u = b & 1u, d = (b >> 1) + 1u;
+            const uint32_t wu = (pair && u) ? w[pair ? j + 1 : j] : w[j];
+            const uint32_t pu = (pair && u) ? prev[pair ? j + 1 : j] : prev[j];
+            const uint32_t key = (uint32_t)((((uint64_t)wu << 32) | pu) >> (2 * d));
+            const uint32_t idx = dense_bloom_index(key);
+            const uint32_t word = lds[idx >> 5];
+            const bool pos = act && __builtin_amdgcn_ubfe(word, idx, 1) != 0;
+            const uint64_t mm = __ballot(pos);
+            if (mm != 0) {
+                if (pos) {
+                    const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
+                    Q.key[q] = key;
+                    Q.off[q] = goff + (uint32_t)(j + (int)u) * 1024u + d; // = window start - span begin + 16
+                }
+                qn += __popcll(mm);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (qn > kDenseQueueCap - 64)
+                    dense_drain(P, Q, qn, false, span_base, lane, lds);
+            }
+        }
+    }
+}
+
+template <int U, int NP>
+__global__ __launch_bounds__(1024) void seed_filter_dense_kernel(const filter_params P)
+{
+    extern __shared__ uint32_t lds[];
+    for (uint32_t i = threadIdx.x; i < P.lds_words; i += blockDim.x)
+        lds[i] = P.bitmap[i];
+    if ((threadIdx.x & 63) == 0) { // this wave's candidate chunk: none drawn yet
+        uint32_t *ck = lds + P.lds_words + kCandLdsSlot + kCandRec * (threadIdx.x >> 6);
+        for (uint32_t i = 0; i < kCandRec; ++i)
+            ck[i] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * waves_per_wg + wave_in_wg;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_wg;
+    dense_queue &Q = *reinterpret_cast<dense_queue *>(lds + P.lds_words + kCandLdsSlot + kCandRec * 16 +
+                                                      (sizeof(dense_queue) / 4) * wave_in_wg);
+    uint32_t qn = 0;
+
+    const uint64_t base0 = P.lo & ~1023ull; // chunks are 1 KiB aligned relative to text[0]
+    const uint64_t n_chunks = (P.hi - base0 + 1023) / 1024;
+    const uint64_t n_whole = (P.hi - base0) / 1024; // chunks that lie fully inside the text
+    const uint64_t span = P.span_chunks;            // multiple of U (host guarantees)
+    const uint64_t n_spans = (n_chunks + span - 1) / span;
+    const uint8_t *lane_text = P.text + base0 + (uint64_t)lane * 16;
+
+    uint64_t sp = wave_id;
+    for (;;) { // (span scheduling as in seed_filter_kernel)
+        if (P.dynamic == 1) {
+            unsigned long long t = 0;
+            if (lane == 0)
+                t = atomicAdd(&P.counters[4], 1ull);
+            sp = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+        } else if (P.dynamic == 2) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned long long t = atomicAdd(&P.counters[4], (unsigned long long)waves_per_wg);
+                lds[P.lds_words] = (uint32_t)t;
+                lds[P.lds_words + 1] = (uint32_t)(t >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lds[P.lds_words + 1]) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane(lds[P.lds_words]);
+            if (base >= n_spans)
+                break;
+            sp = base + wave_in_wg;
+            if (sp >= n_spans)
+                continue;
+        }
+        if (sp >= n_spans)
+            break;
+        const uint64_t c_begin = sp * span;
+        const uint64_t c_end = c_begin + span < n_chunks ? c_begin + span : n_chunks;
+        const uint64_t span_base = base0 + c_begin * 1024;
+        span_open(P, lds, lane, span_base);
+        uint32_t carry_in = 0;
+        {
+            uint32_t nm = 0;
+            if (span_base >= 16 && lane == 0)
+                carry_in = pack16_sig<4>(load_text16(P.text, span_base - 16, P.hi), nm);
+            carry_in = __builtin_amdgcn_readfirstlane(carry_in);
+        }
+        uint64_t ch = c_begin;
+        const uint64_t whole_end = c_end < n_whole ? c_end : n_whole;
+        const uint64_t fast_end = c_begin + (whole_end > c_begin ? (whole_end - c_begin) / U * U : 0);
+        if (ch < fast_end) {
+            uint4 nxt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                nxt[u] = load16_stream<true>(lane_text + (ch + u) * 1024);
+            for (; ch < fast_end; ch += U) {
+                uint4 cur[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    cur[u] = nxt[u];
+                const bool more = ch + U < fast_end;
+                const uint64_t pf = more ? ch + U : ch;
+                const uint64_t ustride = more ? 1024 : 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    nxt[u] = load16_stream<true>(lane_text + pf * 1024 + (uint64_t)u * ustride);
+                __builtin_amdgcn_sched_barrier(0); // the prefetch stays ahead of the group's work
+                dense_group<U, NP>(P, cur, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
+            }
+        }
+        for (; ch < c_end; ++ch) { // ragged end
+            uint4 one[1];
+            one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
+            dense_group<1, NP>(P, one, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
+        }
+        dense_drain(P, Q, qn, true, span_base, lane, lds); // (offsets in the queue are relative to this span)
+        sp += n_waves;
+    }
+    surv_close(P, cand_chunk_of(P, lds), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Optional 2-bit shadow of a dna4 haystack (spm_hip_text_pack): 16 symbols per uint32, same bit order as pack16.
 // A text that is scanned many times (one reference, many needle batches) is then streamed at a quarter of the
 // HBM traffic; hits are identical.  text_pack_kernel builds it in one pass and flags symbols outside {0..3}.
@@ -1049,8 +1211,10 @@ __device__ __forceinline__ uint32_t diff16(const uint4 a, const uint4 b, uint32_
 }
 
 // r = offset of the key window inside its seed (the seeds of a needle with an N do not sit at multiples of q)
-__device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t, uint32_t val, uint32_t r, int64_t hay_b,
-                                            int64_t hay_e)
+// q_whole: the seed's length when the entry spells it (kRngWhole: key + signature are the whole seed; the pieces of a
+// dense pass differ in length), 0: all seeds of the needle are seed_q[needle] long
+__device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t, uint32_t val, uint32_t r, uint32_t q_whole,
+                                            int64_t hay_b, int64_t hay_e)
 {
     if (!P.needle_ranks)
         return true;
@@ -1058,7 +1222,7 @@ __device__ __forceinline__ bool seed_intact(const resolve_params &P, uint64_t t,
     struct
     {
         uint32_t q;
-    } sp{P.seed_q[pat]};
+    } sp{q_whole ? q_whole : P.seed_q[pat]};
     const uint32_t o = x - r; // start of the seed inside the needle
     const int64_t ts = (int64_t)t - (int64_t)r; // where the seed would start in the text
     if (ts < hay_b || ts + (int64_t)sp.q > hay_e)
@@ -1141,19 +1305,6 @@ __device__ __forceinline__ uint32_t pieces_visit(const resolve_params &P, uint64
           (missing << kPieceMissingShift);
     return 1;
 }
-
-// Range code of an exact-table entry (.w):
-//   kRngSingle | r (5 bits) | ns << 5 [| kRngWhole]
-//                 the key sits at this one offset of the needle; its window starts r symbols into its seed; .z = signature:
-//                 the first ns (<= 16) symbols of the rest of the seed; kRngWhole: that IS the whole rest
-//   kRngRun | span
-//                 MANY offsets of the needle share the key (the needle IS a repeat there): no per-offset checks -- they
-//                 would pass wherever the text carries the same repeat --, one pair counted into the bands of the
-//                 diagonals t - offset - span .. t - offset
-constexpr uint32_t kRngRun = 0x8000u;
-constexpr uint32_t kRngSingle = 0x2000u;
-constexpr uint32_t kRngWhole = 0x1000u;
-constexpr uint32_t kSeedChecked = 0x4000u; // (queue only) the signature already showed the whole seed in the text
 
 // The 64 text symbols around a survivor's key window, [t - 16, t + 48), 2 bits each: every entry of the key is checked
 // against them in registers ("does the REST of the seed match too?") instead of with loads per entry -- 73 % of the
@@ -1389,7 +1540,7 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
     const uint32_t pat = val >> 11;
     if (live && !(rng & kRngRun)) {
         if (!(rng & kSeedChecked)) {
-            live = seed_intact(R, t, val, (rng >> 16) & 0x1F, sb, se);
+            live = seed_intact(R, t, val, (rng >> 16) & 0x1F, (rng & kRngWhole) ? R.key_len + ((rng >> 5) & 0x1F) : 0u, sb, se);
             rng |= kSeedChecked;
         }
         through = live;
@@ -1618,7 +1769,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                 if (!(rng & kRngRun)) {
                     const uint32_t r0 = rng & 0x1F, ns = (rng >> 5) & 0x1F;
                     const bool whole = (rng & kRngWhole) != 0;
-                    rng = r0 << 16; // (queued with the pair: where the key window sits in its seed)
+                    // (queued with the pair: where the key window sits in its seed, and the seed's length if the entry knows it)
+                    rng = (r0 << 16) | (whole ? (ns << 5) | kRngWhole : 0u);
                     if (OW.ok) { // does the rest of the seed match?  (registers only)
                         if (!seed_sig_ok(OW, e.y, r0, ns, R.key_len))
                             have = false;

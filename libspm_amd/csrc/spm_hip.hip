@@ -6,6 +6,7 @@
 //   * choose engine, tile the haystack, launch, collect hits       -- the find loop
 // MI355X only; no CPU scan path exists in this library: if HIP fails the call fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +15,9 @@
 #include "brute.hpp"
 #include "common.hpp"
 #include "filter.hpp"
+#include "index_build.hpp"
 #include "synth.hpp"
+#include "tables_build.hpp"
 
 namespace spm_hip
 {
@@ -26,36 +29,7 @@ using namespace spm_hip;
 // ----------------------------------------------------------------------------------------------------
 // pattern set
 // ----------------------------------------------------------------------------------------------------
-struct filter_index
-{
-    // anchored passes: every key begins with a dimer d (sym0 | sym1 << 2) with (d ^ anchor_c) & anchor_cm == 0; cm = 0: unanchored
-    uint32_t anchor_c = 0, anchor_cm = 0;
-    bool ok = false;
-    uint32_t stride = 0;
-    uint32_t key_len = 16;
-    uint32_t bitmap_words = 0;
-    uint32_t n_probes = 0;
-    uint32_t hash_variant = 0;
-    uint32_t lds_words = 0;
-    uint32_t chd_slot_mask = 0, chd_bucket_shift = 0, chd_disp_off = 0;
-    uint32_t ht_mask = 0;
-    uint64_t n_keys = 0;
-    uint64_t n_entries = 0;  // entries of the exact table after identical (key, needle) pairs were merged
-    uint32_t max_range = 0;  // largest diagonal range of a merged entry
-    uint32_t *d_bitmap = nullptr;
-    uint4 *d_ht = nullptr; // key directory: {key, first entry, entries, -}, open addressing, an empty slot has .z == 0
-    // host copies, kept only by spm_hip_host_selftest (no device involved)
-    std::vector<uint32_t> h_image;
-    std::vector<uint4> h_ht; // (the directory)
-};
-
-static thread_local bool g_index_host_only = false;
-// identical (key, needle) entries beyond this many are merged into one with a diagonal range.  (Measured on the 1 % repeat
-// text, 16 / 128 needles across a stretch: > 4: 6.4 / 12.2 ms, > 8: 5.0 / 9.2, > 12: 5.0 / 8.4, > 24: 5.1 / 8.7, never: 5.1 /
-// 9.4 -- merged entries skip the per-offset checks and cost bands, single ones cost checks.)
-constexpr size_t kMergeRun = 12;
-
-struct spm_patterns
+struct spm_patterns : spm_hip::seed_index // (the seed index: passes, entries, seed layout -- index_build.hpp)
 {
     spm_ctx *ctx = nullptr;
     int algo = 0;
@@ -78,577 +52,29 @@ struct spm_patterns
     uint32_t *d_hp0 = nullptr; // prefix: [group][NW][64]
     int32_t *d_m = nullptr;
     int32_t *d_k = nullptr;
-    std::vector<filter_index> fidx; // one per needle sub-batch; empty = the seed filter does not apply
     mutable uint64_t cand_hint = 0; // most candidates a filter scan of this set has produced so far
     uint8_t *d_surplus = nullptr;   // per needle: seeds - k (candidate merging); nullptr = no needle has k >= kMergeMinK
     uint8_t *d_ranks = nullptr;     // filterable sets: the needles' symbols, back to back (whole-seed check of a candidate)
     uint32_t *d_offsets = nullptr;  // ... and where each needle starts
     uint32_t *d_needle_pk = nullptr;  // dna4 sets: the needles 2 bits per symbol, 16 per word (piece count of a candidate)
     uint32_t *d_pk_offsets = nullptr; // ... and the first word of each
-    uint32_t filter_stride = 0;
-    uint32_t filter_key_len = 16;
-    bool filter_anchored = false; // stride 1, one key per seed, chosen to begin with an anchor dimer of its pass
-    uint32_t filter_max_range = 0; // largest diagonal range over all passes
-    // seed layout (filterable sets): needle p has seed_n[p] seeds of seed_q[p] symbols at seed_off[seed_first[p] + j]
-    std::vector<uint16_t> seed_q, seed_n, seed_off;
-    std::vector<uint32_t> seed_first;
     uint16_t *d_seed_q = nullptr;
     pass_entry *d_pass_tab = nullptr; // the passes' key directories, for resolve_kernel
-    std::vector<uint4> h_entries;     // exact entries of all passes, grouped by key: {val = needle << 11 | offset, seed
-                                      // signature, range code, key}
     uint4 *d_entries = nullptr;
     mutable uint64_t hit_hint = 0;    // most hits a filter scan of this set has reported so far (sizes the dedupe set)
     mutable bool scanned = false;     // the hints come from at least one completed filter scan
     mutable int exact_whole = -1;     // 1: k = 0 and every needle is its own single seed (decided at the first scan)
     mutable uint64_t band_hint = 0;   // ... and band-list slots it drew (sizes the verification grid)
+    spm_build_stats build{};          // what spm_hip_patterns_create spent where
 };
 
-static uint32_t next_pow2(uint32_t x)
+using clk = std::chrono::steady_clock;
+static float ms_since(clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); }
+// SPM_HIP_TRACE=1: one stderr line per C-ABI call that does work, with its timings
+static bool spm_trace_on()
 {
-    uint32_t p = 1;
-    while (p < x)
-        p <<= 1;
-    return p;
-}
-
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-struct seed_key // one indexed window: needle p, seed at offset o of the needle, window starting r symbols into the seed
-{
-    uint32_t p, o, r;
-};
-static int build_one_index(spm_ctx *ctx, spm_patterns *ps, const std::vector<seed_key> &items, uint32_t S, filter_index &F);
-
-// A symbol the 2-bit keys can hold: A, C, G, T.  dna5 (seqan3 ranks A0 C1 G2 N3 T4): everything but N; dna15 (A0 B1 C2 D3
-// G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T only.
-static inline bool key_symbol(uint32_t sigma, uint8_t c)
-{
-    return sigma == 4 ? c < 4 : sigma == 5 ? (c < 5 && c != 3) : (c == 0 || c == 2 || c == 4 || c == 11);
-}
-static inline uint32_t key_code(uint32_t sigma, uint8_t c) // 2-bit code of a key symbol
-{
-    return sigma == 4 ? (c & 3u) : sigma == 5 ? (c == 4 ? 3u : c) : (c == 11 ? 3u : (uint32_t)c >> 1);
-}
-
-// Seeds of one needle.  The pigeonhole argument needs n DISJOINT pieces of the needle (n = k + 1, or k + 2 for needles
-// with many errors: two intact pieces on nearby diagonals) -- they need not tile it.  A needle of key symbols only is cut
-// into n pieces of q = floor(m / n) at offsets j * q.  A needle with an N (or, in dna15, any other ambiguity code) takes
-// its pieces from its stretches of key symbols -- the n first pieces of the largest length q that yields n of them --,
-// because a piece with an N can only occur where the text has an N too, and the filter never looks there: an intact
-// piece WITHOUT one is found like any other seed.  false: the needle has no such layout with q >= q_floor.
-static bool layout_seeds(const spm_patterns *ps, uint32_t p, uint32_t q_floor, uint32_t &n_out, uint32_t &q_out,
-                         std::vector<uint16_t> &off)
-{
-    const uint32_t m = (uint32_t)ps->m[p], k = ps->is_myers() ? (uint32_t)ps->k[p] : 0;
-    const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-    bool clean = true;
-    for (uint32_t i = 0; i < m; ++i)
-        clean = clean && key_symbol(ps->sigma, pat[i]);
-    const seed_plan sp = plan_seeds(m, k);
-    off.clear();
-    if (clean) {
-        n_out = sp.n;
-        q_out = sp.q;
-        for (uint32_t j = 0; j < sp.n; ++j)
-            off.push_back((uint16_t)(j * sp.q));
-        return sp.q >= q_floor;
-    }
-    std::vector<std::pair<uint32_t, uint32_t>> runs; // (begin, length) of the stretches of key symbols
-    for (uint32_t i = 0; i < m;) {
-        if (!key_symbol(ps->sigma, pat[i])) {
-            ++i;
-            continue;
-        }
-        uint32_t j = i;
-        while (j < m && key_symbol(ps->sigma, pat[j]))
-            ++j;
-        runs.emplace_back(i, j - i);
-        i = j;
-    }
-    for (uint32_t n : {sp.n, k + 1}) { // (a needle that cannot afford the surplus seed keeps k + 1)
-        for (uint32_t q = m / n; q >= q_floor && q > 0; --q) {
-            uint64_t have = 0;
-            for (const auto &r : runs)
-                have += r.second / q;
-            if (have < n)
-                continue;
-            for (const auto &r : runs)
-                for (uint32_t j = 0; j + q <= r.second && off.size() < n; j += q)
-                    off.push_back((uint16_t)(r.first + j));
-            n_out = n;
-            q_out = q;
-            return true;
-        }
-        if (sp.n == k + 1)
-            break;
-    }
-    return false;
-}
-
-// Seeds of one needle: n pieces of q symbols at offsets j*q.  k+1 pieces guarantee one intact piece per occurrence;
-// needles with many errors get k+2 (two intact pieces on nearby diagonals), which lets the verification stage count seed
-// hits per diagonal band and skip bands with a single one (filter.hpp, candidate merging).
-// Seed filter applicability + partition of the needle set into sub-batches whose keys fit one LDS table.
-static int build_filter_index(spm_ctx *ctx, spm_patterns *ps)
-{
-    ps->fidx.clear();
-    ps->h_entries.clear();
-    if ((ps->sigma != 4 && ps->sigma != 5 && ps->sigma != 15) || ps->algo == SPM_ALGO_MYERS_PREFIX || ps->n == 0 ||
-        ps->n >= (1u << 21))
-        return SPM_OK;
-    uint32_t qmin = 0xFFFFFFFFu;
-    uint64_t n_seeds = 0;
-    ps->seed_q.assign(ps->n, 0);
-    ps->seed_n.assign(ps->n, 0);
-    ps->seed_first.assign(ps->n + 1, 0);
-    ps->seed_off.clear();
-    std::vector<uint16_t> off;
-    for (uint32_t p = 0; p < ps->n; ++p) {
-        const uint32_t m = (uint32_t)ps->m[p];
-        if (m == 0 || m > 2047)
-            return SPM_OK;
-        uint32_t n = 0, q = 0;
-        if (!layout_seeds(ps, p, kKeyMin, n, q, off))
-            return SPM_OK; // (one needle without a layout keeps the whole set on the brute-force engine)
-        ps->seed_q[p] = (uint16_t)q;
-        ps->seed_n[p] = (uint16_t)n;
-        ps->seed_first[p] = (uint32_t)ps->seed_off.size();
-        ps->seed_off.insert(ps->seed_off.end(), off.begin(), off.end());
-        qmin = std::min(qmin, q);
-        n_seeds += n;
-    }
-    ps->seed_first[ps->n] = (uint32_t)ps->seed_off.size();
-    if (qmin < kKeyMin)
-        return SPM_OK;
-    // key length H and stride S: a window of H symbols at every S-th text position needs S <= q - H + 1.
-    // Seeds of >= 17 symbols use full 32-bit keys; shorter seeds give up one or two symbols of key for stride 2
-    // (half the windows), which costs far less than the extra spurious key matches it lets through.
-    // Seeds of <= 12 symbols: the whole seed is the key (stride 1) -- every symbol of key divides the chance matches by 4.
-    uint32_t H = kKeyMax;
-    if (qmin < kKeyMax + 1)
-        H = qmin <= 12 ? qmin : qmin - 1;
-    if ((double)n_seeds / std::pow(4.0, (double)H) > kMaxSurvivorShare)
-        return SPM_OK; // too many keys for their length: most text windows would match one by chance
-    const int force_h = env_int("SPM_HIP_FILTER_KEYLEN", 0);
-    if (force_h >= (int)kKeyMin && force_h <= (int)std::min(qmin, kKeyMax))
-        H = (uint32_t)force_h;
-    uint32_t Smax = 1;
-    while (Smax * 2 <= 16 && Smax * 2 <= qmin - (H - 1))
-        Smax *= 2;
-    const int force_s = env_int("SPM_HIP_FILTER_STRIDE", 0);
-    if (force_s > 0 && (uint32_t)force_s <= Smax)
-        Smax = (uint32_t)force_s;
-    // keys per pass: the fingerprint table has 65536 slots; the hash-and-displace build succeeds up to ~88 % load
-    // (57 344 keys: C4's 400 000 keys take 7 passes instead of the 9 of a 75 % table).  If a dense batch cannot be
-    // placed, the whole set is re-partitioned with smaller batches rather than dropping to the Bloom cascade.
-    const uint64_t cap0 = (uint64_t)std::max(1024, env_int("SPM_HIP_FILTER_MAX_KEYS", 57344));
-    const bool want_chd = env_int("SPM_HIP_FILTER_HASH", 2) == 2;
-    const uint64_t caps[3] = {cap0, cap0 * 7 / 8, cap0 * 3 / 4};
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        const uint64_t cap = caps[attempt];
-        bool dense_failure = false;
-        // stride: the largest one when a single pass suffices; otherwise the one minimising passes x cost per pass
-        // (a pass with stride S looks at 16/S windows per 16 symbols; measured cost grows ~0.3x per doubling)
-        uint32_t S = Smax;
-        if (n_seeds * Smax > cap && force_s <= 0) {
-            double best = 1e300;
-            for (uint32_t s = Smax; s >= 1; s >>= 1) {
-                const double passes = (double)((n_seeds * s + cap - 1) / cap);
-                const double cost = passes * (1.0 + 0.3 * ((double)Smax / s - 1.0));
-                if (cost < best) {
-                    best = cost;
-                    S = s;
-                }
-            }
-        }
-        const uint32_t max_passes = (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_MAX_PASSES", 256));
-        ps->filter_stride = S;
-        ps->filter_key_len = H;
-        // ---- which windows are indexed, and in which pass ----
-        std::vector<std::vector<seed_key>> pass_items;
-        std::vector<uint32_t> pass_anchor;
-        ps->filter_anchored = false;
-        const uint64_t n_passes0 = (n_seeds * S + cap - 1) / cap;
-        if (S == 1 && n_passes0 > 1 && ps->sigma == 4 && H == 16 && qmin > H && env_int("SPM_HIP_FILTER_ANCHOR", 1) != 0) {
-            // Anchored keys.  A set this large gets ONE key per seed (stride 1: every text window is looked up, in every
-            // pass) -- but which of the seed's q - H + 1 windows that is, is ours to choose.  Pass i takes only keys whose
-            // first two symbols (a "dimer", 4 bits: sym0 | sym1 << 2) match ITS anchor pattern: (dimer ^ c) & cm == 0, at
-            // first one dimer per pass (cm = 15).  The streaming kernel then looks up only the text windows that begin
-            // with the anchor -- 1 in 16 -- instead of all: a window beginning with anything else cannot equal a key of the
-            // pass.  Lossless: an intact seed still has its key window in the text.  Each seed goes to a pass in which it
-            // has such a window among its first 32 (fewest choices first, least-loaded pass).  A seed that finds no place
-            // (seeds of 37 symbols, 22 windows, 7 passes: a few in a million) widens a pass's pattern by one don't-care bit -- that pass looks up
-            // 2 in 16 windows.
-            constexpr uint32_t kAnchorWindows = 32; // (an entry records where its window sits in the seed in 5 bits)
-            struct cand
-            {
-                uint32_t p, o, dimers, n_ok; // dimers: bit d set = one of the windows r <= min(31, q - H) begins with d
-            };
-            std::vector<cand> seeds;
-            seeds.reserve(n_seeds);
-            for (uint32_t p = 0; p < ps->n; ++p) {
-                const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-                const uint32_t q = ps->seed_q[p];
-                for (uint32_t j = 0; j < ps->seed_n[p]; ++j) {
-                    const uint32_t o = ps->seed_off[ps->seed_first[p] + j];
-                    uint32_t dm = 0;
-                    for (uint32_t r = 0; r <= std::min<uint32_t>(kAnchorWindows - 1, q - H); ++r)
-                        dm |= 1u << ((pat[o + r] & 3u) | ((pat[o + r + 1] & 3u) << 2));
-                    seeds.push_back({p, o, dm, 0});
-                }
-            }
-            auto dimer_set = [](uint32_t c, uint32_t cm) {
-                uint32_t set = 0;
-                for (uint32_t d = 0; d < 16; ++d)
-                    set |= (((d ^ c) & cm) == 0 ? 1u : 0u) << d;
-                return set;
-            };
-            const uint32_t np_min = (uint32_t)((n_seeds + cap - 1) / cap);
-            for (uint32_t np = np_min; np <= np_min + 1 && pass_items.empty(); ++np) {
-                std::vector<uint32_t> pc(np), pcm(np, 15u), sets(np);
-                for (uint32_t i = 0; i < np; ++i) {
-                    pc[i] = (5u * i + 3u) & 15u; // (a fixed shuffle of the dimers: neighbouring passes differ in both symbols)
-                    sets[i] = dimer_set(pc[i], pcm[i]);
-                }
-                for (cand &c : seeds) {
-                    c.n_ok = 0;
-                    for (uint32_t i = 0; i < np; ++i)
-                        c.n_ok += (c.dimers & sets[i]) ? 1u : 0u;
-                }
-                std::vector<uint32_t> order(seeds.size());
-                for (uint32_t i = 0; i < order.size(); ++i)
-                    order[i] = i;
-                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return seeds[x].n_ok < seeds[y].n_ok; });
-                std::vector<std::vector<uint32_t>> members(np);
-                bool all = true;
-                for (uint32_t idx : order) {
-                    const cand &c = seeds[idx];
-                    uint32_t best = np;
-                    for (uint32_t i = 0; i < np; ++i)
-                        if ((c.dimers & sets[i]) && members[i].size() < cap && (best == np || members[i].size() < members[best].size()))
-                            best = i;
-                    if (best == np) { // no place: widen the narrowest pattern that then takes this seed
-                        uint32_t bbit = 0;
-                        for (uint32_t i = 0; i < np; ++i) {
-                            if (members[i].size() >= cap)
-                                continue;
-                            for (uint32_t bit = 1; bit < 16; bit <<= 1)
-                                if ((pcm[i] & bit) && (c.dimers & dimer_set(pc[i], pcm[i] & ~bit)) &&
-                                    (best == np || __builtin_popcount(pcm[i]) > __builtin_popcount(pcm[best]))) {
-                                    best = i;
-                                    bbit = bit;
-                                }
-                        }
-                        if (best == np) {
-                            all = false;
-                            break;
-                        }
-                        pcm[best] &= ~bbit;
-                        sets[best] = dimer_set(pc[best], pcm[best]);
-                    }
-                    members[best].push_back(idx);
-                }
-                if (!all)
-                    continue;
-                pass_items.resize(np);
-                for (uint32_t i = 0; i < np; ++i) {
-                    for (uint32_t idx : members[i]) {
-                        const cand &c = seeds[idx];
-                        const uint8_t *pat = ps->ranks.data() + ps->offsets[c.p];
-                        uint32_t r = 0;
-                        while (!((sets[i] >> ((pat[c.o + r] & 3u) | ((pat[c.o + r + 1] & 3u) << 2))) & 1u))
-                            ++r;
-                        pass_items[i].push_back({c.p, c.o, r});
-                    }
-                    pass_anchor.push_back(pc[i] | (pcm[i] << 4));
-                }
-                ps->filter_anchored = true;
-            }
-        }
-        if (pass_items.empty()) {
-            uint32_t p0 = 0;
-            while (p0 < ps->n) {
-                uint64_t keys = 0;
-                uint32_t p1 = p0;
-                while (p1 < ps->n) {
-                    const uint64_t add = (uint64_t)ps->seed_n[p1] * S;
-                    if (keys + add > cap && p1 > p0)
-                        break;
-                    keys += add;
-                    ++p1;
-                }
-                pass_items.emplace_back();
-                pass_anchor.push_back(0u); // (no bit of the dimer is compared: every window is looked up)
-                for (uint32_t p = p0; p < p1; ++p)
-                    for (uint32_t j = 0; j < ps->seed_n[p]; ++j)
-                        for (uint32_t r = 0; r < S; ++r)
-                            pass_items.back().push_back({p, ps->seed_off[ps->seed_first[p] + j], r});
-                p0 = p1;
-            }
-        }
-        auto drop_all = [&]() {
-            for (filter_index &G : ps->fidx) {
-                hipFree(G.d_bitmap);
-                hipFree(G.d_ht);
-            }
-            ps->fidx.clear();
-            ps->h_entries.clear();
-        };
-        if (pass_items.size() > max_passes)
-            return SPM_OK; // too many passes to be worth it: brute force
-        for (size_t pi = 0; pi < pass_items.size(); ++pi) {
-            filter_index F;
-            F.key_len = H;
-            F.anchor_c = pass_anchor[pi] & 15u;
-            F.anchor_cm = pass_anchor[pi] >> 4;
-            int rc = build_one_index(ctx, ps, pass_items[pi], S, F);
-            if (rc != SPM_OK)
-                return rc;
-            if (!F.ok) {
-                drop_all();
-                return SPM_OK;
-            }
-            ps->fidx.push_back(F);
-        }
-        ps->filter_max_range = 0;
-        for (const filter_index &F : ps->fidx) {
-            dense_failure = dense_failure || (want_chd && F.hash_variant != 2);
-            ps->filter_max_range = std::max(ps->filter_max_range, F.max_range);
-        }
-        if (!dense_failure || attempt == 2)
-            return SPM_OK;
-        for (filter_index &F : ps->fidx) {
-            hipFree(F.d_bitmap);
-            hipFree(F.d_ht);
-        }
-        ps->fidx.clear();
-    ps->h_entries.clear();
-    }
-    return SPM_OK;
-}
-
-static int build_one_index(spm_ctx *ctx, spm_patterns *ps, const std::vector<seed_key> &items, uint32_t S, filter_index &F)
-{
-    F.ok = false;
-    struct kv
-    {
-        uint32_t key, val, sig, meta;
-    };
-    std::vector<kv> keys;
-    auto code = [&](uint8_t c) -> uint32_t { return key_code(ps->sigma, c); };
-    {
-        {
-            for (const seed_key &it : items) {
-                const uint32_t p = it.p, o = it.o, r = it.r, q = ps->seed_q[p];
-                const uint8_t *pat = ps->ranks.data() + ps->offsets[p];
-                // window seed[r, r+H) -- inside the seed because r <= q - H
-                uint32_t key = 0;
-                for (uint32_t i = 0; i < F.key_len; ++i)
-                    key |= code(pat[o + r + i]) << (2 * i);
-                // signature: the REST of the seed -- its r symbols before the key window, then those after it --, the
-                // first 16 of them, 2 bits each.  With the key that is the whole seed when q <= key_len + 16, so the
-                // resolve kernel checks "the seed occurs here unchanged" in registers (filter.hpp, seed_sig_ok)
-                uint32_t sig = 0, ns = 0;
-                for (uint32_t i = r > 16 ? r - 16 : 0; i < r && ns < 16; ++i, ++ns) // (the 16 symbols next to the window)
-                    sig |= code(pat[o + i]) << (2 * ns);
-                for (uint32_t i = r + F.key_len; i < q && ns < 16; ++i, ++ns)
-                    sig |= code(pat[o + i]) << (2 * ns);
-                // range code of a single entry: where the window sits in its seed (r), how many rest symbols the
-                // signature holds (ns), and whether that is the whole rest (filter.hpp, kRngSingle)
-                const uint32_t meta = kRngSingle | (r & 0x1F) | (ns << 5) | (ns == q - F.key_len ? kRngWhole : 0u);
-                keys.push_back({key, (p << 11) | (o + r), sig, meta});
-            }
-        }
-    }
-    F.n_keys = keys.size();
-    if (F.n_keys == 0)
-        return SPM_OK;
-    // A periodic seed puts the same key at several offsets of one needle (a homopolymer run: at every shift of every
-    // seed).  More than kMergeRun such entries -- the needle IS a repeat there -- are merged into one with a diagonal
-    // range: a text window then yields ONE pair per needle, counted into the bands of all the offsets, without per-offset
-    // checks (they would pass wherever the text carries the same repeat).  Shorter runs -- a needle that merely ends in a
-    // repeat -- stay apart, each with its own seed signature.  (Not for sets whose bands count seed hits: the count
-    // works on single diagonals.)
-    std::vector<uint16_t> ranges(keys.size(), 0);
-    for (size_t i = 0; i < keys.size(); ++i)
-        ranges[i] = (uint16_t)keys[i].meta;
-    const bool band_merging = ps->max_k >= kMergeMinK && ps->max_k <= 1000;
-    if (!band_merging && env_int("SPM_HIP_FILTER_DEDUPE", 1) != 0) {
-        std::sort(keys.begin(), keys.end(), [](const kv &a, const kv &b) { return a.key != b.key ? a.key < b.key : a.val < b.val; });
-        size_t w = 0;
-        for (size_t i = 0; i < keys.size();) {
-            size_t j = i + 1;
-            while (j < keys.size() && keys[j].key == keys[i].key && (keys[j].val >> 11) == (keys[i].val >> 11))
-                ++j;
-            if (j - i > (size_t)std::max(1, env_int("SPM_HIP_FILTER_MERGE_RUN", (int)kMergeRun))) {
-                const uint32_t span = (keys[j - 1].val & 0x7FF) - (keys[i].val & 0x7FF);
-                keys[w] = keys[i];
-                ranges[w] = (uint16_t)(kRngRun | span);
-                F.max_range = std::max<uint32_t>(F.max_range, span);
-                ++w;
-            } else {
-                for (size_t q = i; q < j; ++q) {
-                    keys[w] = keys[q];
-                    ranges[w] = (uint16_t)keys[q].meta;
-                    ++w;
-                }
-            }
-            i = j;
-        }
-        keys.resize(w);
-        ranges.resize(w);
-    }
-    F.n_entries = keys.size();
-    F.stride = S;
-    F.n_probes = (uint32_t)std::max(1, std::min(4, env_int("SPM_HIP_FILTER_PROBES", 4)));
-    F.hash_variant = (uint32_t)std::max(0, std::min(2, env_int("SPM_HIP_FILTER_HASH", 2)));
-    std::vector<uint32_t> image; // what every workgroup stages into LDS
-    if (F.hash_variant == 2) {
-        // ---- perfect-hash fingerprint table (hash-and-displace, see filter.hpp) ----
-        std::vector<uint32_t> uniq;
-        uniq.reserve(keys.size());
-        for (const kv &e : keys)
-            uniq.push_back(e.key);
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-        uint32_t n_slots = 1024;
-        while (n_slots < 2 * uniq.size() && n_slots < 65536)
-            n_slots <<= 1;
-        bool ok = uniq.size() <= (size_t)(0.96 * n_slots);
-        const uint32_t n_buckets = std::max(64u, n_slots / 8);
-        uint32_t lg = 0;
-        while ((1u << lg) < n_buckets)
-            ++lg;
-        const uint32_t shift = 32 - lg;
-        std::vector<uint16_t> fp(n_slots, 0xFFFF), disp(n_buckets, 0);
-        if (ok) {
-            std::vector<std::vector<uint32_t>> buckets(n_buckets);
-            for (uint32_t k : uniq)
-                buckets[chd_hash(k).x >> shift].push_back(k);
-            std::vector<uint32_t> order(n_buckets);
-            for (uint32_t b = 0; b < n_buckets; ++b)
-                order[b] = b;
-            std::sort(order.begin(), order.end(),
-                      [&](uint32_t a, uint32_t b) { return buckets[a].size() > buckets[b].size(); });
-            std::vector<uint8_t> used(n_slots, 0);
-            std::vector<uint32_t> slots;
-            for (uint32_t b : order) {
-                const auto &B = buckets[b];
-                if (B.empty())
-                    break;
-                bool placed = false;
-                for (uint32_t d = 0; d < 65536 && !placed; ++d) {
-                    slots.clear();
-                    bool good = true;
-                    for (uint32_t k : B) {
-                        const uint32_t sl = chd_slot(chd_hash(k), d, n_slots - 1);
-                        if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) {
-                            good = false;
-                            break;
-                        }
-                        slots.push_back(sl);
-                    }
-                    if (good) {
-                        for (size_t i = 0; i < B.size(); ++i) {
-                            used[slots[i]] = 1;
-                            fp[slots[i]] = (uint16_t)chd_hash(B[i]).f;
-                        }
-                        disp[b] = (uint16_t)d;
-                        placed = true;
-                    }
-                }
-                if (!placed) {
-                    ok = false;
-                    break;
-                }
-            }
-        }
-        if (ok) {
-            F.chd_slot_mask = n_slots - 1;
-            F.chd_bucket_shift = shift;
-            F.chd_disp_off = n_slots * 2;
-            image.resize((n_slots * 2 + n_buckets * 2) / 4);
-            memcpy(image.data(), fp.data(), n_slots * 2);
-            memcpy((uint8_t *)image.data() + n_slots * 2, disp.data(), n_buckets * 2);
-            F.bitmap_words = (uint32_t)image.size();
-        } else {
-            F.hash_variant = 1; // key set too dense for the fingerprint table: Bloom cascade
-        }
-    }
-    if (ps->sigma != 4 && F.hash_variant != 2)
-        return SPM_OK; // the dna5 kernel is built for the fingerprint table only
-    if (F.hash_variant != 2) {
-        uint64_t want_bits = F.n_keys * 32;
-        uint32_t words = 1024;
-        while ((uint64_t)words * 32 < want_bits && words < 32768)
-            words <<= 1;
-        const int force_w = env_int("SPM_HIP_FILTER_BITMAP_WORDS", 0);
-        if (force_w >= 256 && force_w <= 32768 && (force_w & (force_w - 1)) == 0)
-            words = (uint32_t)force_w;
-        F.bitmap_words = words;
-        image.assign(words, 0);
-        const uint32_t idx_mask = words * 32 - 1;
-        for (const kv &e : keys)
-            for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
-                const uint32_t hh = (F.hash_variant ? bloom_hash<1>(e.key, pr) : bloom_hash<0>(e.key, pr)) & idx_mask;
-                image[hh >> 5] |= 1u << (hh & 31);
-            }
-    }
-    F.lds_words = (uint32_t)image.size();
-    const uint32_t words = F.lds_words;
-    const std::vector<uint32_t> &bitmap = image;
-    // Exact level: a directory key -> (first entry, count) with open addressing, and the entries of a key side by side
-    // in one array (all passes share it).  A survivor costs one short directory probe; its entries -- a key that twenty
-    // needles share has twenty -- are then dealt to the lanes of the wave one pair each (resolve_kernel), instead of one
-    // lane walking a probe sequence while 63 wait.
-    {
-        std::vector<size_t> order(keys.size());
-        for (size_t i = 0; i < order.size(); ++i)
-            order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a].key < keys[b].key; });
-        std::vector<kv> k2(keys.size());
-        std::vector<uint16_t> r2(keys.size());
-        for (size_t i = 0; i < order.size(); ++i) {
-            k2[i] = keys[order[i]];
-            r2[i] = ranges[order[i]];
-        }
-        keys.swap(k2);
-        ranges.swap(r2);
-    }
-    size_t n_distinct = 0;
-    for (size_t i = 0; i < keys.size(); ++i)
-        n_distinct += (i == 0 || keys[i].key != keys[i - 1].key) ? 1 : 0;
-    uint32_t ht_size = next_pow2((uint32_t)std::max<uint64_t>(1024, n_distinct * 2));
-    F.ht_mask = ht_size - 1;
-    std::vector<uint4> ht(ht_size, make_uint4(0, 0, 0, 0));
-    for (size_t i = 0; i < keys.size();) {
-        size_t j = i;
-        while (j < keys.size() && keys[j].key == keys[i].key)
-            ++j;
-        uint32_t slot = ht_hash(keys[i].key) & F.ht_mask;
-        while (ht[slot].z != 0)
-            slot = (slot + 1) & F.ht_mask;
-        ht[slot] = make_uint4(keys[i].key, (uint32_t)ps->h_entries.size(), (uint32_t)(j - i), 0);
-        for (size_t q = i; q < j; ++q)
-            ps->h_entries.push_back(make_uint4(keys[q].val, keys[q].sig, ranges[q], keys[q].key));
-        i = j;
-    }
-    if (g_index_host_only) {
-        F.h_image = bitmap;
-        F.h_ht = ht;
-        F.ok = true;
-        return SPM_OK;
-    }
-    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_bitmap, words * sizeof(uint32_t)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&F.d_ht, ht_size * sizeof(uint4)));
-    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_bitmap, bitmap.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SPM_HIP_CHECK(ctx, hipMemcpy(F.d_ht, ht.data(), ht_size * sizeof(uint4), hipMemcpyHostToDevice));
-    F.ok = true;
-    return SPM_OK;
+    const char *v = getenv("SPM_HIP_TRACE");
+    return v && *v && *v != '0';
 }
 
 extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ranks_concat, const uint32_t *offsets,
@@ -660,7 +86,8 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         return SPM_E_INVALID;
     }
     SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    std::unique_ptr<spm_patterns> ps(new spm_patterns);
+    const auto t_begin = clk::now();
+    std::unique_ptr<spm_patterns, void (*)(spm_patterns *)> ps(new spm_patterns, spm_hip_patterns_destroy); // (error paths free the device side too)
     ps->ctx = ctx;
     ps->algo = algo;
     ps->n = n_patterns;
@@ -688,149 +115,114 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         ps->max_window = std::max(ps->max_window, m + kk);
     }
     ps->NW = next_pow2(std::max(1u, (ps->max_m + 31) / 32));
-    const uint32_t NW = ps->NW, rows = sigma + 1;
-    const bool myers = ps->is_myers();
+    const uint32_t NW = ps->NW;
+    const index_tuning tune = index_tuning::from_env();
+    ps->build.threads = tune.n_threads();
+    needle_view nv;
+    nv.algo = algo;
+    nv.n = n_patterns;
+    nv.sigma = sigma;
+    nv.ranks = ps->ranks.data();
+    nv.offsets = ps->offsets.data();
+    nv.m = ps->m.data();
+    nv.k = ps->k.data();
+    nv.max_k = ps->max_k;
+    auto upload = [&](auto **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(bytes, 16));
+        if (e == hipSuccess && bytes)
+            e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    double ms_upload = 0;
+    auto t0 = clk::now();
 
-    // ---- brute tables: [group][row][word][lane], needles top-aligned (see brute.hpp) ----
-    std::vector<uint32_t> peq((size_t)ps->n_groups * rows * NW * 64, 0);
-    std::vector<uint32_t> hp0;
-    if (algo == SPM_ALGO_MYERS_PREFIX)
-        hp0.assign((size_t)ps->n_groups * NW * 64, 0);
-    for (uint32_t g = 0; g < ps->n_groups; ++g)
-        for (uint32_t l = 0; l < 64; ++l) {
-            const uint32_t p = g * 64 + l;
-            const uint32_t m = p < n_patterns ? (uint32_t)ps->m[p] : 0;
-            const uint32_t off = NW * 32 - m;
-            auto word = [&](uint32_t row, uint32_t w) -> uint32_t & {
-                return peq[(((size_t)g * rows + row) * NW + w) * 64 + l];
-            };
-            if (myers) {
-                // Peq: bit set = match.  wildcard rows (bits < off) match every symbol, also the invalid one
-                if (m > 0)
-                    for (uint32_t row = 0; row < rows; ++row)
-                        for (uint32_t b = 0; b < off; ++b)
-                            word(row, b / 32) |= 1u << (b % 32);
-                for (uint32_t j = 0; j < m; ++j) {
-                    const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                    if (c < sigma)
-                        word(c, (off + j) / 32) |= 1u << ((off + j) % 32);
-                }
-                if (algo == SPM_ALGO_MYERS_PREFIX && m > 0)
-                    hp0[((size_t)g * NW + off / 32) * 64 + l] = 1u << (off % 32);
-            } else {
-                // Shift-Or masks: bit CLEAR = match; wildcard bits clear for every row
-                for (uint32_t row = 0; row < rows; ++row)
-                    for (uint32_t w = 0; w < NW; ++w)
-                        word(row, w) = 0xFFFFFFFFu;
-                if (m > 0)
-                    for (uint32_t row = 0; row < rows; ++row)
-                        for (uint32_t b = 0; b < off; ++b)
-                            word(row, b / 32) &= ~(1u << (b % 32));
-                for (uint32_t j = 0; j < m; ++j) {
-                    const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                    if (c < sigma)
-                        word(c, (off + j) / 32) &= ~(1u << ((off + j) % 32));
-                }
-            }
-        }
-    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq, peq.size() * sizeof(uint32_t)));
-    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq, peq.data(), peq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!myers && (sigma <= 5 || sigma == 15)) {
-        // the filter engine verifies exact matchers with the Myers recurrence at k = 0: match masks, not Shift-Or's
-        std::vector<uint32_t> vq(peq.size(), 0);
-        for (uint32_t p = 0; p < n_patterns; ++p) {
-            const uint32_t m = (uint32_t)ps->m[p];
-            if (m == 0)
-                continue;
-            const uint32_t off = NW * 32 - m, g = p / 64, l = p % 64;
-            for (uint32_t row = 0; row < rows; ++row)
-                for (uint32_t b = 0; b < off; ++b)
-                    vq[(((size_t)g * rows + row) * NW + b / 32) * 64 + l] |= 1u << (b % 32);
-            for (uint32_t j = 0; j < m; ++j) {
-                const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                if (c < sigma)
-                    vq[(((size_t)g * rows + c) * NW + (off + j) / 32) * 64 + l] |= 1u << ((off + j) % 32);
-            }
-        }
-        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq_verify, vq.size() * sizeof(uint32_t)));
-        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq_verify, vq.data(), vq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // ---- match-mask tables: [group][row][word][lane], needles top-aligned (see brute.hpp) ----
+    {
+        brute_tables bt;
+        build_brute_tables(nv, ps->n_groups, NW, sigma <= 5 || sigma == 15, tune.n_threads(), bt);
+        ps->build.ms_tables = ms_since(t0);
+        const auto tu = clk::now();
+        SPM_HIP_CHECK(ctx, upload(&ps->d_peq, bt.peq.data(), bt.peq.size() * sizeof(uint32_t)));
+        if (!bt.verify.empty()) // the filter engine verifies exact matchers with the Myers recurrence at k = 0
+            SPM_HIP_CHECK(ctx, upload(&ps->d_peq_verify, bt.verify.data(), bt.verify.size() * sizeof(uint32_t)));
+        if (!bt.bot.empty())
+            SPM_HIP_CHECK(ctx, upload(&ps->d_peq_bot, bt.bot.data(), bt.bot.size() * sizeof(uint32_t)));
+        if (!bt.hp0.empty())
+            SPM_HIP_CHECK(ctx, upload(&ps->d_hp0, bt.hp0.data(), bt.hp0.size() * sizeof(uint32_t)));
+        SPM_HIP_CHECK(ctx, upload(&ps->d_m, ps->m.data(), ps->m.size() * sizeof(int32_t)));
+        SPM_HIP_CHECK(ctx, upload(&ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t)));
+        ms_upload += ms_since(tu);
     }
-    if (algo == SPM_ALGO_MYERS) {
-        std::vector<uint32_t> bot(peq.size(), 0);
-        for (uint32_t p = 0; p < n_patterns; ++p)
-            for (uint32_t j = 0; j < (uint32_t)ps->m[p]; ++j) {
-                const uint8_t c = ps->ranks[ps->offsets[p] + j];
-                if (c < sigma)
-                    bot[((((size_t)(p / 64)) * rows + c) * NW + j / 32) * 64 + (p % 64)] |= 1u << (j % 32);
-            }
-        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_peq_bot, bot.size() * sizeof(uint32_t)));
-        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_peq_bot, bot.data(), bot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    if (!hp0.empty()) {
-        SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_hp0, hp0.size() * sizeof(uint32_t)));
-        SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_hp0, hp0.data(), hp0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_m, ps->m.size() * sizeof(int32_t)));
-    SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_k, ps->k.size() * sizeof(int32_t)));
-    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_m, ps->m.data(), ps->m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 
     // ---- filter engine tables (verification reads the brute table) ----
     if ((sigma == 4 || sigma == 5 || sigma == 15) && algo != SPM_ALGO_MYERS_PREFIX && n_patterns > 0) {
-        int rc = build_filter_index(ctx, ps.get());
+        const auto ti = clk::now();
+        int rc = build_filter_index(nv, tune, *ps);
         if (rc != SPM_OK)
             return rc;
+        ps->build.ms_index = ms_since(ti);
+        const auto tu = clk::now();
         if (!ps->fidx.empty()) {
             std::vector<pass_entry> pt;
-            for (const filter_index &F : ps->fidx)
-                pt.push_back(pass_entry{F.d_ht, F.ht_mask, 0});
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_pass_tab, pt.size() * sizeof(pass_entry)));
-            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_pass_tab, pt.data(), pt.size() * sizeof(pass_entry), hipMemcpyHostToDevice));
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_entries, std::max<size_t>(ps->h_entries.size(), 1) * sizeof(uint4)));
-            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_entries, ps->h_entries.data(), ps->h_entries.size() * sizeof(uint4),
-                                         hipMemcpyHostToDevice));
-            ps->h_entries.clear();
-            ps->h_entries.shrink_to_fit();
+            for (filter_index &F : ps->fidx) {
+                SPM_HIP_CHECK(ctx, upload(&F.d_bitmap, F.h_image.data(), F.h_image.size() * sizeof(uint32_t)));
+                SPM_HIP_CHECK(ctx, upload(&F.d_ht, F.h_ht.data(), F.h_ht.size() * sizeof(u32x4)));
+                if (F.dense)
+                    SPM_HIP_CHECK(ctx, upload(&F.d_buckets, F.h_buckets.data(), F.h_buckets.size() * sizeof(uint16_t)));
+                ps->build.keys += F.n_keys;
+                for (uint32_t d = 0; d < 16; ++d)
+                    ps->build.anchor_sixteenths += (F.dimer_set >> d) & 1u;
+                F.h_image = std::vector<uint32_t>();
+                F.h_ht = std::vector<u32x4>();
+                F.h_buckets = std::vector<uint16_t>();
+                pt.push_back(pass_entry{reinterpret_cast<const uint4 *>(F.d_ht), F.ht_mask, 0});
+            }
+            SPM_HIP_CHECK(ctx, upload(&ps->d_pass_tab, pt.data(), pt.size() * sizeof(pass_entry)));
+            SPM_HIP_CHECK(ctx, upload(&ps->d_entries, ps->h_entries.data(), ps->h_entries.size() * sizeof(u32x4)));
+            ps->h_entries = std::vector<u32x4>();
             const size_t nr = ps->ranks.size() + 64; // padded: resolve_kernel reads whole dwords around a seed
             SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_ranks, nr));
             SPM_HIP_CHECK(ctx, hipMemset(ps->d_ranks, 0, nr));
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_offsets, ps->offsets.size() * sizeof(uint32_t)));
             if (!ps->ranks.empty())
                 SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
-            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t),
-                                         hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, upload(&ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t)));
             if (ps->sigma == 4) { // the same symbols 2 bits each, 16 per word, every needle from a word of its own
-                std::vector<uint32_t> pk, pk_off(ps->n, 0);
-                for (uint32_t p = 0; p < ps->n; ++p) {
-                    pk_off[p] = (uint32_t)pk.size();
-                    const uint8_t *nd = ps->ranks.data() + ps->offsets[p];
-                    const uint32_t m = (uint32_t)ps->m[p];
-                    for (uint32_t y = 0; y < m; y += 16) {
-                        uint32_t w = 0;
-                        for (uint32_t i = 0; i < 16 && y + i < m; ++i)
-                            w |= (uint32_t)(nd[y + i] & 3) << (2 * i);
-                        pk.push_back(w);
-                    }
-                }
-                pk.push_back(0);
-                SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_needle_pk, pk.size() * sizeof(uint32_t)));
-                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_needle_pk, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-                SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_pk_offsets, pk_off.size() * sizeof(uint32_t)));
-                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_pk_offsets, pk_off.data(), pk_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                std::vector<uint32_t> pk, pk_off;
+                pack_needles(nv, pk, pk_off);
+                SPM_HIP_CHECK(ctx, upload(&ps->d_needle_pk, pk.data(), pk.size() * sizeof(uint32_t)));
+                SPM_HIP_CHECK(ctx, upload(&ps->d_pk_offsets, pk_off.data(), pk_off.size() * sizeof(uint32_t)));
             }
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_seed_q, ps->seed_q.size() * sizeof(uint16_t)));
-            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_seed_q, ps->seed_q.data(), ps->seed_q.size() * sizeof(uint16_t),
-                                         hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, upload(&ps->d_seed_q, ps->seed_q.data(), ps->seed_q.size() * sizeof(uint16_t)));
         }
         if (!ps->fidx.empty() && ps->max_k >= kMergeMinK && ps->max_k <= 1000) {
             std::vector<uint8_t> surplus(ps->m.size(), 1);
             for (uint32_t p = 0; p < ps->n; ++p)
                 surplus[p] = (uint8_t)(ps->seed_n[p] - (uint32_t)ps->k[p]);
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_surplus, surplus.size()));
-            SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_surplus, surplus.data(), surplus.size(), hipMemcpyHostToDevice));
+            SPM_HIP_CHECK(ctx, upload(&ps->d_surplus, surplus.data(), surplus.size()));
         }
+        ms_upload += ms_since(tu);
     }
+    ps->build.ms_upload = (float)ms_upload;
+    ps->build.ms_total = ms_since(t_begin);
+    ps->build.passes = (uint32_t)ps->fidx.size();
+    ps->build.dense = ps->filter_dense ? 1u : 0u;
+    ps->build.stride = ps->filter_stride;
+    ps->build.key_len = ps->filter_key_len;
+    if (spm_trace_on())
+        fprintf(stderr, "[spm_hip] patterns_create: %u needles, algo %d, sigma %u -> %u pass(es)%s, %llu keys, %u/16 of the dimers; "
+                        "%.2f ms (tables %.2f, index %.2f, upload %.2f; %u threads)\n",
+                n_patterns, algo, sigma, ps->build.passes, ps->build.dense ? " dense" : "", (unsigned long long)ps->build.keys,
+                ps->build.anchor_sixteenths, ps->build.ms_total, ps->build.ms_tables, ps->build.ms_index, ps->build.ms_upload,
+                ps->build.threads);
     *out = ps.release();
+    return SPM_OK;
+}
+
+extern "C" int spm_hip_patterns_build_stats(const spm_patterns *p, spm_build_stats *out)
+{
+    if (!p || !out)
+        return SPM_E_INVALID;
+    *out = p->build;
     return SPM_OK;
 }
 
@@ -855,6 +247,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
     for (filter_index &F : p->fidx) {
         hipFree(F.d_bitmap);
         hipFree(F.d_ht);
+        hipFree(F.d_buckets);
     }
     delete p;
 }
@@ -1700,9 +1093,16 @@ int run_filter(const scan_args &A)
     P.pass = (uint32_t)fi;
     P.anchor_c = F.anchor_c;
     P.anchor_cm = F.anchor_cm;
+    P.n_pat = F.n_pat;
+    for (uint32_t i = 0; i < kDensePatterns; ++i) {
+        P.pat_c[i] = F.pat_c[i];
+        P.pat_cm[i] = F.pat_cm[i];
+    }
+    P.bucket_shift = F.bucket_shift;
+    P.buckets = reinterpret_cast<const uint4 *>(F.d_buckets);
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
-    const bool use_packed = A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
+    const bool use_packed = !F.dense && A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
                             !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
     // measured best: 8 waves per CU on the 1-byte text when HBM binds, 16 on the 2-bit shadow and at stride 1 with
     // 16-symbol keys (LDS-bound: C4 25.8 vs 29.1 ms; the other stride-1/2 variants need more than 128 VGPRs)
@@ -1711,10 +1111,10 @@ int run_filter(const scan_args &A)
     const bool narrow2 = F.stride == 2 && !use_packed && env_int("SPM_HIP_FILTER_S2_U", 2) == 2;
     const bool wide_ok = use_packed || narrow2 || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
                                                    !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
-    const uint32_t threads = (uint32_t)std::max(
+    const uint32_t threads = F.dense ? 1024u : (uint32_t)std::max(
         64, std::min(wide_ok ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", wide_ok ? 1024 : 512)));
-    // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave
-    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4;
+    // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave (+ dense: one queue per wave)
+    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4 + (F.dense ? 16 * sizeof(dense_queue) : 0);
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
@@ -1801,7 +1201,21 @@ int run_filter(const scan_args &A)
         else                                                                                                           \
             LAUNCH_FILTER2(S, (UMAX >= 4 ? 4 : UMAX));                                                                 \
     } while (0)
-    if (use_packed) {
+    if (F.dense) {
+#define LAUNCH_DENSE(NP)                                                                                               \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_dense_kernel<4, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                                 \
+        hipLaunchKernelGGL((seed_filter_dense_kernel<4, NP>), dim3(grid), dim3(threads), lds, ctx->stream, P);         \
+    } while (0)
+        if (F.n_pat <= 1)
+            LAUNCH_DENSE(1);
+        else if (F.n_pat == 2)
+            LAUNCH_DENSE(2);
+        else
+            LAUNCH_DENSE(3);
+#undef LAUNCH_DENSE
+    } else if (use_packed) {
         // p-chunks of 4096 symbols: recompute the span geometry in those units
         filter_params Q = P;
         const uint64_t n_pchunks = (Q.hi - (Q.lo & ~4095ull) + 4095) / 4096;
@@ -2558,165 +1972,11 @@ extern "C" void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, ui
 
 extern "C" uint64_t spm_hip_mix64(uint64_t z) { return mix64(z); }
 
-// Host-only self-check of the seed index (no device, no context): builds the tables exactly as
-// spm_hip_patterns_create does and verifies the properties the filter's losslessness rests on.
+// Host-only self-check of the seed index (no device, no context): index_build.hpp
 extern "C" int spm_hip_host_selftest(int algo, const uint8_t *ranks_concat, const uint32_t *offsets, uint32_t n_patterns,
                                      const uint16_t *k, uint32_t sigma, uint64_t *stats)
 {
-    if (!ranks_concat || !offsets || !stats || n_patterns == 0)
-        return SPM_E_INVALID;
-    spm_patterns ps;
-    ps.algo = algo;
-    ps.n = n_patterns;
-    ps.sigma = sigma;
-    ps.offsets.assign(offsets, offsets + n_patterns + 1);
-    ps.ranks.assign(ranks_concat, ranks_concat + offsets[n_patterns]);
-    ps.m.assign(n_patterns, 0);
-    ps.k.assign(n_patterns, 0);
-    for (uint32_t p = 0; p < n_patterns; ++p) {
-        ps.m[p] = (int32_t)(offsets[p + 1] - offsets[p]);
-        ps.k[p] = (ps.is_myers() && k) ? k[p] : 0;
-        ps.max_k = std::max<uint32_t>(ps.max_k, (uint32_t)ps.k[p]);
-    }
-    g_index_host_only = true;
-    const int rc = build_filter_index(nullptr, &ps);
-    g_index_host_only = false;
-    memset(stats, 0, 8 * sizeof(uint64_t));
-    if (rc != SPM_OK)
-        return rc;
-    stats[0] = ps.fidx.size();   // passes (0 = the seed filter does not apply)
-    stats[1] = ps.filter_stride | ((uint64_t)ps.filter_key_len << 32); // S | H << 32
-    if (ps.fidx.empty())
-        return SPM_OK;
-    const uint32_t S = ps.filter_stride;
-    // level-1 membership test, exactly as the kernels evaluate it
-    auto level1 = [&](const filter_index &F, uint32_t key) -> bool {
-        if (F.hash_variant == 2) {
-            const uint16_t *fp = reinterpret_cast<const uint16_t *>(F.h_image.data());
-            const uint16_t *disp = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(F.h_image.data()) + F.chd_disp_off);
-            const chd_hashes hh = chd_hash(key);
-            const uint32_t d = disp[hh.x >> F.chd_bucket_shift];
-            return fp[chd_slot(hh, d, F.chd_slot_mask)] == hh.f;
-        }
-        const uint32_t idx_mask = F.bitmap_words * 32 - 1;
-        for (uint32_t pr = 0; pr < F.n_probes; ++pr) {
-            const uint32_t x = (F.hash_variant ? bloom_hash<1>(key, pr) : bloom_hash<0>(key, pr)) & idx_mask;
-            if (!((F.h_image[x >> 5] >> (x & 31)) & 1))
-                return false;
-        }
-        return true;
-    };
-    auto level2 = [&](const filter_index &F, uint32_t key, uint32_t val) -> bool {
-        uint32_t slot = ht_hash(key) & F.ht_mask;
-        for (;;) {
-            const uint4 d = F.h_ht[slot];
-            if (d.z == 0)
-                return false;
-            if (d.x == key) {
-                for (uint32_t q = 0; q < d.z; ++q) {
-                    const uint4 e = ps.h_entries[d.y + q];
-                    if (e.w != key)
-                        return false; // the entries of a key lie side by side
-                    if ((e.x >> 11) == (val >> 11)) {
-                        // the entry itself, or a run whose diagonal range covers this offset
-                        const uint32_t x0 = e.x & 0x7FF, x = val & 0x7FF;
-                        if (!(e.z & kRngRun) ? x == x0 : (x >= x0 && x <= x0 + (e.z & 0x7FF)))
-                            return true;
-                    }
-                }
-                return false;
-            }
-            slot = (slot + 1) & F.ht_mask;
-        }
-    };
-    // every needle belongs to exactly one pass; every indexed window of every seed is found at both levels
-    uint64_t checked = 0, missing = 0;
-    {
-        uint64_t keys_total = 0;
-        for (const filter_index &F : ps.fidx)
-            keys_total += F.n_keys;
-        stats[2] = keys_total;
-        uint64_t expect = 0;
-        for (uint32_t p = 0; p < n_patterns; ++p)
-            expect += (uint64_t)ps.seed_n[p] * S;
-        if (expect != keys_total)
-            return SPM_E_INVALID;
-    }
-    size_t fi = 0;
-    uint64_t in_pass = 0;
-    for (uint32_t p = 0; p < n_patterns; ++p) {
-        const uint32_t q = ps.seed_q[p], sn = ps.seed_n[p];
-        if (S > q - (ps.filter_key_len - 1) || sn < (ps.is_myers() ? (uint32_t)ps.k[p] : 0u) + 1)
-            return SPM_E_INVALID; // sampling would miss occurrences / too few seeds for the pigeonhole argument
-        for (uint32_t j = 0; j < sn; ++j) { // seeds: inside the needle, disjoint, key symbols only
-            const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
-            if (o + q > (uint32_t)ps.m[p] || (j && o < ps.seed_off[ps.seed_first[p] + j - 1] + q))
-                return SPM_E_INVALID;
-            for (uint32_t i = 0; i < q; ++i)
-                if (!key_symbol(sigma, ps.ranks[ps.offsets[p] + o + i]))
-                    return SPM_E_INVALID;
-        }
-        if (ps.filter_anchored) {
-            // every seed has ONE key, in one pass, and that key begins with an anchor dimer of the pass (so the streaming
-            // kernel, which looks up only such windows, meets it)
-            const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
-            for (uint32_t j = 0; j < sn; ++j) {
-                const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
-                uint32_t found = 0;
-                for (const filter_index &F : ps.fidx)
-                    for (uint32_t r = 0; r + ps.filter_key_len <= q && r < 32; ++r) {
-                        uint32_t key = 0;
-                        for (uint32_t i = 0; i < ps.filter_key_len; ++i)
-                            key |= key_code(sigma, pat[o + r + i]) << (2 * i);
-                        if ((((key & 0xF) ^ F.anchor_c) & F.anchor_cm) == 0 && level1(F, key) && level2(F, key, (p << 11) | (o + r)))
-                            ++found;
-                    }
-                ++checked;
-                if (found < 1)
-                    ++missing;
-            }
-            continue;
-        }
-        const uint64_t mine = (uint64_t)sn * S;
-        while (fi < ps.fidx.size() && in_pass + mine > ps.fidx[fi].n_keys) {
-            if (in_pass != ps.fidx[fi].n_keys)
-                return SPM_E_INVALID;
-            ++fi;
-            in_pass = 0;
-        }
-        if (fi >= ps.fidx.size())
-            return SPM_E_INVALID;
-        in_pass += mine;
-        const filter_index &F = ps.fidx[fi];
-        const uint8_t *pat = ps.ranks.data() + ps.offsets[p];
-        for (uint32_t j = 0; j < sn; ++j)
-            for (uint32_t r = 0; r < S; ++r) {
-                const uint32_t o = ps.seed_off[ps.seed_first[p] + j];
-                uint32_t key = 0;
-                for (uint32_t i = 0; i < ps.filter_key_len; ++i)
-                    key |= key_code(sigma, pat[o + r + i]) << (2 * i);
-                ++checked;
-                if (!level1(F, key) || !level2(F, key, (p << 11) | (o + r)))
-                    ++missing;
-            }
-    }
-    uint64_t anchor_sum = 0; // dimers looked up, over all passes
-    for (const filter_index &F : ps.fidx)
-        anchor_sum += 1ull << (4 - __builtin_popcount(F.anchor_cm));
-    stats[3] = checked;
-    stats[4] = missing;
-    // false-positive rate of level 1 on pseudo-random keys (first pass)
-    uint64_t fp = 0;
-    const uint64_t trials = 1 << 20;
-    for (uint64_t t = 0; t < trials; ++t)
-        fp += level1(ps.fidx[0], (uint32_t)mix64(0xC0FFEE + t) &
-                                     (ps.filter_key_len >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ps.filter_key_len)) - 1)))
-                  ? 1
-                  : 0;
-    stats[5] = fp;
-    stats[6] = trials;
-    stats[7] = ps.fidx[0].hash_variant | (ps.filter_anchored ? anchor_sum << 8 : 0);
-    return missing ? SPM_E_INVALID : SPM_OK;
+    return spm_hip::host_selftest(algo, ranks_concat, offsets, n_patterns, k, sigma, stats);
 }
 
 extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.1 (gfx950)"; }

@@ -7,17 +7,10 @@
 #pragma once
 
 #include "common.hpp"
+#include "hd.hpp" // mix64
 
 namespace spm_hip
 {
-
-__host__ __device__ inline uint64_t mix64(uint64_t z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 
 __host__ __device__ inline uint8_t synth_base(uint64_t seed, uint64_t i)
 {

@@ -141,6 +141,12 @@ class PatternSet:
     def filterable(self) -> bool:
         return bool(capi.lib().spm_hip_patterns_filterable(self._h))
 
+    def build_stats(self) -> capi.BuildStats:
+        """What spm_hip_patterns_create spent where (host ms) and what it built (passes, keys, dense, anchors)."""
+        st = capi.BuildStats()
+        _check(capi.lib().spm_hip_patterns_build_stats(self._h, C.byref(st)), self.ctx._h)
+        return st
+
     def state_stride(self) -> int:
         return int(capi.lib().spm_hip_patterns_state_stride(self._h))
 

@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 def _patterns(ctx, spm, needles, k, max_keys):
     os.environ["SPM_HIP_FILTER_MAX_KEYS"] = str(max_keys)
     os.environ["SPM_HIP_FILTER_STRIDE"] = "1"
+    os.environ["SPM_HIP_FILTER_DENSE"] = "0"    # (sets of several stride-1 passes go to the dense pass by default: test_gpu_dense.py)
     try:
         return ctx.patterns(spm.ALGO_MYERS, needles, k=k)
     finally:
         os.environ.pop("SPM_HIP_FILTER_MAX_KEYS", None)
         os.environ.pop("SPM_HIP_FILTER_STRIDE", None)
+        os.environ.pop("SPM_HIP_FILTER_DENSE", None)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "low_complexity", "many_passes"])

@@ -388,6 +388,7 @@ def test_filter_sub_batches_equal_single_pass(spm, ctx, oracle):
     needles = _planted_config(spm, oracle, n, 300, 150, 3)
     want = None
     for max_keys, stride in ((None, None), (4096, None), (1500, 4), (1024, 1)):
+        os.environ["SPM_HIP_FILTER_DENSE"] = "0"    # (the sparse passes are the subject; the dense pass: test_gpu_dense.py)
         if max_keys:
             os.environ["SPM_HIP_FILTER_MAX_KEYS"] = str(max_keys)
         if stride:
@@ -397,6 +398,7 @@ def test_filter_sub_batches_equal_single_pass(spm, ctx, oracle):
         finally:
             os.environ.pop("SPM_HIP_FILTER_MAX_KEYS", None)
             os.environ.pop("SPM_HIP_FILTER_STRIDE", None)
+            os.environ.pop("SPM_HIP_FILTER_DENSE", None)
         assert ps.filterable
         h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
         st = h.stats()

@@ -19,7 +19,8 @@ def _selftest(spm, algo, needles, k, sigma=4):
                                               ks.ctypes.data_as(C.POINTER(C.c_uint16)), sigma, stats)
     names = ["passes", "stride", "keys", "checked", "missing", "fp", "trials", "hash_variant"]
     st = dict(zip(names, [int(x) for x in stats]))
-    st["anchor_dimers"] = st["hash_variant"] >> 8
+    st["anchor_dimers"] = (st["hash_variant"] >> 8) & 0xFF
+    st["deep"] = st["hash_variant"] >> 16       # dense pass: needles whose pieces overlap (c > 1)
     st["hash_variant"] &= 0xFF
     st["key_len"] = st["stride"] >> 32
     st["stride"] &= 0xFFFFFFFF
@@ -43,24 +44,29 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     big = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(6000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, big, 3)
     assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["stride"] == 2 and st["keys"] == 6000 * 4 * 2
-    # 20 000 needles: 80 000 seeds do not fit one table (57 344 keys) even at stride 1 -> sub-batches; the cost model
-    # prefers three passes at stride 2 to two at stride 1
-    rc, st = _selftest(spm, spm.ALGO_MYERS, big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)], 3)
-    assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (3, 2, 160000)
-    assert st["hash_variant"] == 2
-    # a C4-sized set: 400 000 seeds at stride 1, one key per seed.  Anchored: every seed's key begins with the dimer of
-    # its pass (the streaming kernel looks up only the text windows that begin with it); a few passes take two dimers
+    # 20 000 needles: 80 000 seeds do not fit one table (57 344 keys) even at stride 1.  Sparse passes: sub-batches; the
+    # cost model prefers three passes at stride 2 to two at stride 1.  (By default such a set takes the dense pass, below.)
+    big20 = big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)]
     c4 = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(100000)]
-    rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
-    assert rc == 0 and st["missing"] == 0 and (st["stride"], st["keys"], st["checked"]) == (1, 400000, 400000)
-    assert st["passes"] == 7 and st["hash_variant"] == 2 and 7 <= st["anchor_dimers"] <= 14  # (dimers over all passes)
-    os.environ["SPM_HIP_FILTER_ANCHOR"] = "0"
+    os.environ["SPM_HIP_FILTER_DENSE"] = "0"
     try:
+        rc, st = _selftest(spm, spm.ALGO_MYERS, big20, 3)
+        assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (3, 2, 160000)
+        assert st["hash_variant"] == 2
+        # a C4-sized set: 400 000 seeds at stride 1, one key per seed.  Anchored: every seed's key begins with the dimer of
+        # its pass (the streaming kernel looks up only the text windows that begin with it); a few passes take two dimers
         rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
+        assert rc == 0 and st["missing"] == 0 and (st["stride"], st["keys"], st["checked"]) == (1, 400000, 400000)
+        assert st["passes"] == 7 and st["hash_variant"] == 2 and 7 <= st["anchor_dimers"] <= 14  # (dimers over all passes)
+        os.environ["SPM_HIP_FILTER_ANCHOR"] = "0"
+        try:
+            rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
+        finally:
+            del os.environ["SPM_HIP_FILTER_ANCHOR"]
+        assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (7, 1, 400000)
+        assert st["hash_variant"] == 2 and st["anchor_dimers"] == 0
     finally:
-        del os.environ["SPM_HIP_FILTER_ANCHOR"]
-    assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (7, 1, 400000)
-    assert st["hash_variant"] == 2 and st["anchor_dimers"] == 0
+        del os.environ["SPM_HIP_FILTER_DENSE"]
     # mixed lengths and k: the stride follows the shortest seed
     mixed = [rng.integers(0, 4, m, dtype=np.uint8) for m in (64, 100, 150, 300, 1000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, mixed, [3, 3, 5, 10, 40])
@@ -119,3 +125,47 @@ def test_dna5_and_bloom_fallback(spm):
         del os.environ["SPM_HIP_FILTER_HASH"]
     assert rc == 0 and st["hash_variant"] == 1 and st["missing"] == 0
     assert st["fp"] / st["trials"] < 2e-3                            # 4 probes at 12.5 % occupancy
+
+
+def test_dense_pass_index(spm):
+    """Sets that would need several sparse passes (or stride 1) get ONE dense pass: every needle has c k + 1 pieces, no
+    position in more than c of them, every piece holds a 16-symbol key that begins with an anchor dimer and is found at
+    all three levels (presence bit, fingerprint bucket, directory entry) -- the self-check verifies exactly that."""
+    rng = np.random.default_rng(5)
+    c4 = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(100000)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["hash_variant"] == 3
+    assert (st["stride"], st["key_len"]) == (1, 16) and 400000 <= st["keys"] <= 420000 and st["checked"] == st["keys"]
+    assert 2 <= st["anchor_dimers"] <= 3                     # 1/8 .. 3/16 of the text windows are looked up
+    assert st["fp"] / st["trials"] < 2e-4                    # a random window: anchored AND bit set AND fingerprint equal
+    # the shape of the reference's own read set (100 000 x 100, k <= 3): less room per piece, more anchors
+    r100 = [rng.integers(0, 4, 100, dtype=np.uint8) for _ in range(100000)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, r100, 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["hash_variant"] == 3 and 3 <= st["anchor_dimers"] <= 6
+    # needles whose windows offer a single dimer (poly-A, (AC)n) decide which anchors are usable at all
+    odd = c4[:20000] + [np.zeros(150, np.uint8), np.resize(np.array([0, 1], np.uint8), 150),
+                        np.resize(np.array([2, 3, 3], np.uint8), 150)]
+    rc, st = _selftest(spm, spm.ALGO_MYERS, odd, 3)
+    assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["hash_variant"] == 3 and st["anchor_dimers"] <= 8
+    # a small set, forced: needles of exactly (k + 1) x 16 symbols have one layout only (keys at 0, 16, 32, 48): the anchor
+    # set grows until it covers them -- every window, then
+    os.environ["SPM_HIP_FILTER_DENSE"] = "2"
+    try:
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 64, dtype=np.uint8) for _ in range(300)], 3)
+        assert rc == 0 and st["missing"] == 0 and st["hash_variant"] == 3 and st["anchor_dimers"] == 16
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 100, dtype=np.uint8) for _ in range(300)], 3)
+        assert rc == 0 and st["missing"] == 0 and st["hash_variant"] == 3
+        # exact matchers: one piece per needle
+        rc, st = _selftest(spm, spm.ALGO_SHIFTOR, [rng.integers(0, 4, 40, dtype=np.uint8) for _ in range(300)], 0)
+        assert rc == 0 and st["missing"] == 0 and st["hash_variant"] == 3 and st["keys"] == 300
+    finally:
+        del os.environ["SPM_HIP_FILTER_DENSE"]
+    # not for sets the dense pass cannot hold: needles shorter than (k + 1) x 16, sets with k >= 8
+    os.environ["SPM_HIP_FILTER_DENSE"] = "2"
+    try:
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8) for _ in range(100)], 3)
+        assert rc == 0 and st["hash_variant"] == 2
+        rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 1024, dtype=np.uint8) for _ in range(8)], 64)
+        assert rc == 0 and st["hash_variant"] == 2
+    finally:
+        del os.environ["SPM_HIP_FILTER_DENSE"]
