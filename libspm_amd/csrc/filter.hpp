@@ -117,6 +117,7 @@ struct filter_params
     // dense passes (filter_shared.hpp): lds = presence bits; a window is looked up iff its dimer matches one of the n_pat patterns
     uint32_t n_pat, pat_c[kDensePatterns], pat_cm[kDensePatterns];
     uint32_t bucket_shift;
+    uint32_t dense_debug;     // diagnostics (SPM_HIP_DENSE_DEBUG): 1 drop the windows that pass level 1, 2 skip level 1 too, 4 gather from 256 buckets only (L1 hits; wrong hits)
     const uint4 *buckets;     // fingerprint buckets, L2-resident
     survivor *surv;
     unsigned long long *counters; // [1] = survivor slots drawn, [6] = spans that gave up, [2] = hard overflow
@@ -736,7 +737,7 @@ __device__ __forceinline__ void dense_drain(const filter_params &P, dense_queue 
             if (v[b]) {
                 key[b] = Q.key[e];
                 off[b] = Q.off[e];
-                bk[b] = P.buckets[dense_bucket(key[b], P.bucket_shift)];
+                bk[b] = P.buckets[dense_bucket(key[b], P.bucket_shift) & ((P.dense_debug & 4u) ? 255u : 0xFFFFFFFFu)];
             }
         }
         qn = qn > 64 * nb ? qn - 64 * nb : 0;
@@ -779,34 +780,48 @@ __device__ __forceinline__ void dense_group(const filter_params &P, const uint4 
 #pragma unroll
     for (int j = 0; j < UU; j += 2) {
         constexpr bool pair = UU > 1;
+        const uint32_t w0 = w[j], p0 = prev[j], w1 = w[pair ? j + 1 : j], p1 = prev[pair ? j + 1 : j];
         // the anchored windows of two words in one mask: bit b = word j + (b & 1), window (b >> 1) + 1
-        uint32_t todo = dense_select<NP>(P, w[j], prev[j]);
+        uint32_t todo = dense_select<NP>(P, w0, p0);
         if (pair)
-            todo |= dense_select<NP>(P, w[pair ? j + 1 : j], prev[pair ? j + 1 : j]) << 1;
-        while (__ballot(todo != 0) != 0) {
-            const bool act = todo != 0;
-            const uint32_t b = act ? (uint32_t)__ffs(todo) - 1u : 0u;
+            todo |= dense_select<NP>(P, w1, p1) << 1;
+        // level 1, every lane for itself (a lane runs as long as it has anchored windows -- no wave-wide steps in here, the
+        // loop is what this kernel spends its time in): which of them have their presence bit set
+        uint32_t pm = 0;
+        if (P.dense_debug & 2u)
+            todo = 0;
+        while (todo != 0) {
+            const uint32_t b = (uint32_t)__ffs(todo) - 1u;
             todo &= todo - 1;
-            const uint32_t u = b & 1u, d = (b >> 1) + 1u;
-            const uint32_t wu = (pair && u) ? w[pair ? j + 1 : j] : w[j];
-            const uint32_t pu = (pair && u) ? prev[pair ? j + 1 : j] : prev[j];
-            const uint32_t key = (uint32_t)((((uint64_t)wu << 32) | pu) >> (2 * d));
-            const uint32_t idx = dense_bloom_index(key);
-            const uint32_t word = lds[idx >> 5];
-            const bool pos = act && __builtin_amdgcn_ubfe(word, idx, 1) != 0;
+            const bool odd = (b & 1u) != 0;
+            const uint64_t both = ((uint64_t)(odd ? w1 : w0) << 32) | (odd ? p1 : p0);
+            const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u)); // window d = (b >> 1) + 1 starts 2 d bits in
+            const uint32_t h = key ^ (key >> 13); // dense_bloom_index(key) = h & (2^20 - 1): word h >> 5, bit h & 31
+            static_assert(kDenseBloomBits == 20, "the word address below takes bits 5..19 of the index");
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + ((h >> 3) & 0x1FFFCu));
+            pm |= __builtin_amdgcn_ubfe(word, h, 1) << b;
+        }
+        // level 1b: those that do wait in the queue until the wave has a batch of them (wave-wide steps from here on)
+        if (P.dense_debug & 1u)
+            pm = 0;
+        while (__ballot(pm != 0) != 0) {
+            const bool pos = pm != 0;
+            const uint32_t b = pos ? (uint32_t)__ffs(pm) - 1u : 0u;
+            pm &= pm - 1;
+            const bool odd = (b & 1u) != 0;
+            const uint64_t both = ((uint64_t)(odd ? w1 : w0) << 32) | (odd ? p1 : p0);
+            const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u));
             const uint64_t mm = __ballot(pos);
-            if (mm != 0) {
-                if (pos) {
-                    const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
-                    Q.key[q] = key;
-                    Q.off[q] = goff + (uint32_t)(j + (int)u) * 1024u + d; // = window start - span begin + 16
-                }
-                qn += __popcll(mm);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (qn > kDenseQueueCap - 64)
-                    dense_drain(P, Q, qn, false, span_base, lane, lds);
+            if (pos) {
+                const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
+                Q.key[q] = key;
+                Q.off[q] = goff + (uint32_t)j * 1024u + (odd ? 1024u : 0u) + (b >> 1) + 1u; // = window start - span begin + 16
             }
+            qn += __popcll(mm);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (qn > kDenseQueueCap - 64)
+                dense_drain(P, Q, qn, false, span_base, lane, lds);
         }
     }
 }

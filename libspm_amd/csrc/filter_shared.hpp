@@ -99,9 +99,11 @@ constexpr uint32_t kDenseBloomBits = 20;          // 2^20 bits = 128 KiB of LDS
 constexpr uint32_t kDenseSlots = 8;               // 16-bit slots per 16-byte bucket
 constexpr uint32_t kDenseAcceptAll = 0x7FFFu;     // last slot of a bucket that overflowed at build time: every window passes
 
-SPM_HD inline uint32_t dense_bloom_index(uint32_t key) // bit index in the presence table (the anchor dimer, bits 0..3, says nothing)
+SPM_HD inline uint32_t dense_bloom_index(uint32_t key) // bit index in the presence table
 {
-    return ((key >> 4) ^ (key >> 17)) & ((1u << kDenseBloomBits) - 1); // symbols 2..11, folded with 8.5..15
+    // every key bit takes part: bits 0..19 as they are, bits 13..31 folded onto 0..18.  (The kernel never forms this index:
+    // its word address is (h >> 3) & 0x1FFFC and its bit h & 31, with h = key ^ key >> 13 -- five VALU per window.)
+    return (key ^ (key >> 13)) & ((1u << kDenseBloomBits) - 1);
 }
 SPM_HD inline uint32_t dense_bucket(uint32_t key, uint32_t bucket_shift) { return (key * 0x9E3779B1u) >> bucket_shift; }
 SPM_HD inline uint32_t dense_fp(uint32_t key) { return 0x8000u | ((key ^ (key >> 15) ^ (key >> 23)) & 0x7FFFu); }

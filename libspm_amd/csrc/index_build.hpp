@@ -14,6 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -50,6 +53,7 @@ struct index_tuning
     int dense_min_density = 0; // force at least this many sixteenths of the dimers as anchors (diagnostics)
     int dense_max_density = 8; // a set that needs more than this many sixteenths keeps its sparse passes (dense = 2: no limit)
     int dense_cmax = 4;     // pieces of a needle may overlap up to this many deep (c k + 1 pieces then)
+    int dense_sweeps = 2;   // rounds of key re-selection that make needles share presence bits (0: first-fit keys)
     int threads = 0;        // 0: hardware concurrency, at most 16
     static index_tuning from_env()
     {
@@ -68,6 +72,7 @@ struct index_tuning
         T.dense_min_density = env_int("SPM_HIP_FILTER_DENSE_MIN_DENSITY", 0);
         T.dense_max_density = std::max(2, std::min(16, env_int("SPM_HIP_FILTER_DENSE_MAX_DENSITY", 8)));
         T.dense_cmax = std::max(1, std::min(8, env_int("SPM_HIP_FILTER_DENSE_CMAX", 4)));
+        T.dense_sweeps = std::max(0, std::min(8, env_int("SPM_HIP_FILTER_DENSE_SWEEPS", 2)));
         T.threads = env_int("SPM_HIP_BUILD_THREADS", 0);
         return T;
     }
@@ -78,6 +83,82 @@ struct index_tuning
         const unsigned hc = std::thread::hardware_concurrency();
         return std::max(1u, std::min(16u, hc ? hc : 1u));
     }
+};
+
+// A team of worker threads that lives as long as one index build: run(n, fn) calls fn(begin, end, thread) over [0, n) in
+// contiguous slices, one per thread (the caller takes slice 0).  The rounds of dense_share_bits start 64 of these; spawning
+// threads for each would cost more than the work.
+class thread_team
+{
+  public:
+    explicit thread_team(unsigned n) : n_(std::max(1u, n))
+    {
+        for (unsigned t = 1; t < n_; ++t)
+            workers_.emplace_back([this, t]() { loop(t); });
+    }
+    ~thread_team()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        for (std::thread &w : workers_)
+            w.join();
+    }
+    unsigned size() const { return n_; }
+    template <typename F>
+    void run(size_t n, F fn)
+    {
+        if (n_ <= 1 || n < 2) {
+            fn((size_t)0, n, 0u);
+            return;
+        }
+        std::function<void(unsigned)> job = [&](unsigned t) { fn(n * t / n_, n * (t + 1) / n_, t); };
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job;
+            pending_ = n_ - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&]() { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(unsigned t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&]() { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_)
+                    return;
+                job = job_;
+            }
+            (*job)(t);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_.notify_one();
+            }
+        }
+    }
+    unsigned n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
 };
 
 // fn(begin, end, thread) over [0, n) in contiguous slices
@@ -739,6 +820,125 @@ inline bool choose_dense_anchors(const needle_view &nv, const index_tuning &T, d
     return false;
 }
 
+// Which windows become keys decides how many presence bits are set, i.e. how many text windows pass level 1 and cost a
+// gather from L2 -- the resource the dense pass runs out of first.  A needle usually has several layouts (150 symbols, 3/16
+// of the dimers: ~25 anchored windows for 4 keys), so every needle with disjoint pieces (c = 1) takes the layout whose keys
+// hit the most bits that OTHER needles have set already (dynamic programme over its anchored windows: best number of shared
+// bits with j keys from window i on).  Needles are taken in rounds of n / 32: a round reads the bit counts the rounds before it
+// left (and its own needles' previous choice, which does not count), then its changes are applied -- the result does not
+// depend on the number of threads.  Two sweeps (the first needles chose when the table was empty): random 150-symbol
+// needles, k = 3, 100 000 of them: 31.7 % of the 2^20 bits set with first-fit keys, 18.4 % after one sweep, 16.0 % after two.
+inline void dense_share_bits(const needle_view &nv, const index_tuning &T, uint32_t dimers, const std::vector<uint8_t> &cc,
+                             const std::vector<uint32_t> &first, std::vector<uint16_t> &pos_flat)
+{
+    if (T.dense_sweeps <= 0)
+        return;
+    thread_team team(T.n_threads());
+    std::vector<uint16_t> ref(1u << kDenseBloomBits, 0); // keys per presence bit
+    auto key_at = [&](const uint8_t *pat, uint32_t i) {
+        uint32_t key = 0;
+        for (uint32_t x = 0; x < kKeyMax; ++x)
+            key |= (uint32_t)(pat[i + x] & 3u) << (2 * x);
+        return key;
+    };
+    std::vector<uint8_t> placed(nv.n, 0); // the needle's keys are counted in ref
+    std::vector<uint32_t> bit_of(pos_flat.size(), 0), fresh_bit(pos_flat.size(), 0); // presence bit of every chosen key
+    for (uint32_t p = 0; p < nv.n; ++p)
+        if (cc[p] != 1) { // (overlapping pieces keep their first-fit keys)
+            for (uint32_t s = first[p]; s < first[p + 1]; ++s)
+                ++ref[bit_of[s] = dense_bloom_index(key_at(nv.ranks + nv.offsets[p], pos_flat[s]))];
+            placed[p] = 1;
+        }
+    constexpr uint32_t kRounds = 24;
+    std::vector<uint16_t> fresh(pos_flat.size());
+    for (int sweep = 0; sweep < T.dense_sweeps; ++sweep)
+        for (uint32_t round = 0; round < kRounds; ++round) {
+            const size_t rb = (size_t)nv.n * round / kRounds, re = (size_t)nv.n * (round + 1) / kRounds;
+            team.run(re - rb, [&](size_t b, size_t e, unsigned) {
+                std::vector<uint16_t> cpos;
+                std::vector<uint32_t> cbit, nxt;
+                std::vector<uint8_t> shared;
+                std::vector<int16_t> dp;
+                for (size_t p = rb + b; p < rb + e; ++p) {
+                    const uint32_t need = first[p + 1] - first[p];
+                    if (cc[p] != 1 || need == 0)
+                        continue;
+                    const uint8_t *pat = nv.ranks + nv.offsets[p];
+                    const uint32_t m = (uint32_t)nv.m[p];
+                    uint32_t own[kDenseMaxPieces];
+                    for (uint32_t j = 0; j < need; ++j)
+                        own[j] = placed[p] ? bit_of[first[p] + j] : 0xFFFFFFFFu;
+                    // the anchored windows, their bits, and whether somebody else has set them
+                    cpos.clear();
+                    cbit.clear();
+                    shared.clear();
+                    uint32_t key = key_at(pat, 0);
+                    for (uint32_t i = 0; i + kKeyMax <= m; ++i) {
+                        if (i)
+                            key = (key >> 2) | ((uint32_t)(pat[i + kKeyMax - 1] & 3u) << 30);
+                        if (!((dimers >> (key & 15u)) & 1u))
+                            continue;
+                        const uint32_t bit = dense_bloom_index(key);
+                        uint32_t mine = 0;
+                        for (uint32_t j = 0; j < need; ++j)
+                            mine += own[j] == bit ? 1u : 0u;
+                        cpos.push_back((uint16_t)i);
+                        cbit.push_back(bit);
+                        shared.push_back(ref[bit] > mine ? 1 : 0);
+                    }
+                    const uint32_t nc = (uint32_t)cpos.size();
+                    nxt.assign(nc + 1, nc); // first candidate that does not overlap candidate i
+                    for (uint32_t i = 0, t = 0; i < nc; ++i) {
+                        while (t < nc && cpos[t] < cpos[i] + kKeyMax)
+                            ++t;
+                        nxt[i] = t;
+                    }
+                    // dp[j][i]: most shared bits with j keys among candidates i.., -1: no such layout
+                    dp.assign((size_t)(need + 1) * (nc + 1), -1);
+                    for (uint32_t i = 0; i <= nc; ++i)
+                        dp[i] = 0;
+                    for (uint32_t j = 1; j <= need; ++j)
+                        for (uint32_t i = nc; i-- > 0;) {
+                            const int16_t skip = dp[(size_t)j * (nc + 1) + i + 1];
+                            const int16_t rest = dp[(size_t)(j - 1) * (nc + 1) + nxt[i]];
+                            const int16_t take = rest < 0 ? (int16_t)-1 : (int16_t)(rest + shared[i]);
+                            dp[(size_t)j * (nc + 1) + i] = take >= skip ? take : skip;
+                        }
+                    if (dp[(size_t)need * (nc + 1)] < 0) { // (cannot happen: first fit found a layout)
+                        for (uint32_t j = 0; j < need; ++j) {
+                            fresh[first[p] + j] = pos_flat[first[p] + j];
+                            fresh_bit[first[p] + j] = dense_bloom_index(key_at(pat, pos_flat[first[p] + j]));
+                        }
+                        continue;
+                    }
+                    for (uint32_t i = 0, j = need; j >= 1;) {
+                        const int16_t rest = dp[(size_t)(j - 1) * (nc + 1) + nxt[i]];
+                        const int16_t take = rest < 0 ? (int16_t)-1 : (int16_t)(rest + shared[i]);
+                        if (take >= 0 && take == dp[(size_t)j * (nc + 1) + i] && take >= dp[(size_t)j * (nc + 1) + i + 1]) {
+                            fresh[first[p] + (need - j)] = cpos[i];
+                            fresh_bit[first[p] + (need - j)] = cbit[i];
+                            i = nxt[i];
+                            --j;
+                        } else {
+                            ++i;
+                        }
+                    }
+                }
+            });
+            for (size_t p = rb; p < re; ++p) { // the round's changes
+                if (cc[p] != 1)
+                    continue;
+                for (uint32_t s = first[p]; s < first[p + 1]; ++s) {
+                    if (placed[p])
+                        --ref[bit_of[s]];
+                    pos_flat[s] = fresh[s];
+                    ++ref[bit_of[s] = fresh_bit[s]];
+                }
+                placed[p] = 1;
+            }
+        }
+}
+
 inline bool index_trace_on()
 {
     const char *v = getenv("SPM_HIP_TRACE");
@@ -757,14 +957,12 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
     const auto t1 = iclk::now();
     const unsigned nt = T.n_threads();
     const uint32_t cmax = (uint32_t)T.dense_cmax;
-    // ---- layouts, per needle (threads): key positions first, then the keys laid out back to back ----
+    // ---- layouts, per needle (threads): key positions first (first fit), then the keys laid out back to back ----
     std::vector<uint8_t> cc(nv.n, 0), nn(nv.n, 0);
     std::vector<uint32_t> first(nv.n + 1, 0);
     std::vector<std::vector<uint16_t>> pos_of(nt); // thread t: the positions of its slice of needles, back to back
-    std::vector<size_t> slice_begin(nt + 1, nv.n);
     parallel_slices(nv.n, nt, [&](size_t b, size_t e, unsigned t) {
         uint16_t pos[kDenseMaxPieces];
-        slice_begin[t] = b;
         std::vector<uint16_t> &out = pos_of[t];
         out.reserve((e - b) * 5);
         for (size_t p = b; p < e; ++p) {
@@ -778,6 +976,16 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
     for (uint32_t p = 0; p < nv.n; ++p)
         first[p + 1] = first[p] + nn[p];
     const size_t n_keys = first[nv.n];
+    std::vector<uint16_t> pos_flat(n_keys);
+    {
+        size_t at = 0;
+        for (unsigned t = 0; t < nt; ++t) { // (the slices of parallel_slices are contiguous and ascending)
+            std::copy(pos_of[t].begin(), pos_of[t].end(), pos_flat.begin() + at);
+            at += pos_of[t].size();
+            pos_of[t] = std::vector<uint16_t>();
+        }
+    }
+    dense_share_bits(nv, T, A.dimers, cc, first, pos_flat);
     X.seed_q.assign(nv.n, 0);
     X.seed_n.assign(nv.n, 0);
     X.seed_c.assign(nv.n, 1);
@@ -785,10 +993,9 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
     X.seed_off.assign(n_keys, 0);
     X.seed_len.assign(n_keys, 0);
     std::vector<index_kv> keys(n_keys);
-    parallel_slices(nv.n, nt, [&](size_t b, size_t e, unsigned t) {
-        // (the same slices as above, or one slice for all when the set is too small for threads)
-        const uint16_t *pos = pos_of[t].data();
+    parallel_slices(nv.n, nt, [&](size_t b, size_t e, unsigned) {
         for (size_t p = b; p < e; ++p) {
+            const uint16_t *pos = pos_flat.data() + first[p];
             const uint32_t m = (uint32_t)nv.m[p], c = cc[p], n = nn[p];
             X.seed_n[p] = (uint16_t)n;
             X.seed_c[p] = (uint8_t)c;
@@ -809,7 +1016,6 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
                 X.seed_len[s] = (uint16_t)(hi - lo);
                 keys[s] = make_kv(nv, seed_key{(uint32_t)p, lo, pos[j] - lo, hi - lo}, kKeyMax);
             }
-            pos += n;
         }
     });
     const double ms_layout = ms(t1);
@@ -858,9 +1064,14 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
     for (size_t i = 0; i < keys.size(); ++i)
         ranges[i] = (uint16_t)keys[i].meta;
     build_directory(keys, ranges, F, X.h_entries);
-    if (index_trace_on())
-        fprintf(stderr, "[spm_hip] dense index: %zu keys, anchors %u/16 (%u pattern(s)); anchors %.2f ms, layouts %.2f, bits + buckets %.2f, "
-                        "directory %.2f (%u threads)\n", n_keys, A.sixteenths(), A.n_pat, ms_anchors, ms_layout, ms_level1, ms(t3), nt);
+    if (index_trace_on()) {
+        uint64_t set = 0;
+        for (uint32_t w : F.h_image)
+            set += (uint64_t)__builtin_popcount(w);
+        fprintf(stderr, "[spm_hip] dense index: %zu keys, anchors %u/16 (%u pattern(s)), %.1f %% of the presence bits set; anchors %.2f ms, "
+                        "layouts %.2f, bits + buckets %.2f, directory %.2f (%u threads)\n", n_keys, A.sixteenths(), A.n_pat,
+                100.0 * (double)set / (double)(1u << kDenseBloomBits), ms_anchors, ms_layout, ms_level1, ms(t3), nt);
+    }
     F.ok = true;
     X.fidx.push_back(std::move(F));
     X.filter_stride = 1;

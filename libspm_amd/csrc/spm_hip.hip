@@ -1099,6 +1099,7 @@ int run_filter(const scan_args &A)
         P.pat_cm[i] = F.pat_cm[i];
     }
     P.bucket_shift = F.bucket_shift;
+    P.dense_debug = (uint32_t)env_int("SPM_HIP_DENSE_DEBUG", 0);
     P.buckets = reinterpret_cast<const uint4 *>(F.d_buckets);
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
