@@ -303,6 +303,9 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
+    host = host_cpu_facts()
+    if host.get("cgroup_quota_cpus"):  # a cgroup CPU quota: more threads than that only take turns
+        cores = min(cores, max(1, int(host["cgroup_quota_cpus"] + 0.999)))
     cores = max(1, min(cores, 64))
     o_algo = O.MYERS if algo == "myers" else O.SHIFTOR
     pats = [O.pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(64)]
@@ -323,7 +326,11 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
     return {
         "value": lane_steps / n_pat_full / 1e9,
         "unit": "Gbases/s",
-        "cores": cores,
+        "cores": cores,   # threads used = CPUs this process may run on (affinity, capped by the cgroup CPU quota), at most 64
+        # how many cores' worth of work those threads got: all-threads rate / one-thread rate (SMT siblings and a cgroup
+        # CPU quota both show up here); `value` derives from the measured all-threads rate only
+        "effective_cores": lane_steps / rate1,
+        "host": host,
         "kind": "port",
         "lane_steps_per_s": lane_steps,
         # one needle, one thread, one symbol: the serial VP/VN dependency chain of the bit-vector recurrence
@@ -336,6 +343,46 @@ def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
                   f"needle over {cores} threads, best of 2; value = measured lane-steps/s / {n_pat_full} needles "
                   f"(linear extrapolation to the full needle set); {len(hits)} hits",
     }
+
+
+def host_cpu_facts():
+    """Physical cores, hardware threads and the cgroup CPU quota of this host, as far as /proc and /sys tell."""
+    facts = {"logical_cpus": os.cpu_count()}
+    try:
+        facts["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        phys = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        if phys:
+            facts["physical_cores"] = len(phys)
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                facts["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    facts["cgroup_quota_cpus"] = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                facts["cgroup_quota_cpus"] = q / per if q > 0 else None
+            break
+        except Exception:
+            continue
+    return facts
 
 
 def self_launch(argv, n):
@@ -465,6 +512,11 @@ def other_configs(args, env):
              "hits": r["hits"], "all_planted_found": r["all_planted_found"], "fell_back": r["fell_back"],
              "candidates": r["candidates"], "verify_ms_per_step": r["verify_ms_per_step"],
              "setup_and_run_s": time.perf_counter() - t0}
+        for k in ("patterns_create_ms", "patterns_create", "first_scan_ms"):
+            if k in r:
+                o[k] = r[k]
+        if "traffic" in rf and rf["traffic"] is not None:
+            o["roofline"]["traffic"] = rf["traffic"]
         for k in ("fallback_spans", "repeat_text", "needles_found_on_their_haplotype", "journaled_sequence_tree",
                   "fanout_ms_per_step", "parity_slice"):
             if k in r:
@@ -498,7 +550,14 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         text = ctx.generate(SEED_TEXT, lo - ovl, (hi - lo) + ovl)
         needles = [S.synth_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(n_pat)]
     s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR
+    # matcher construction (the reference: one constructor per needle, myers_matcher.hpp:40-43): host wall clock of the
+    # call that builds every table of the set and uploads it -- not part of a step, reported beside it
+    torch.cuda.synchronize()
+    t_create = time.perf_counter()
     ps = ctx.patterns(s_algo, needles, k=kmax)
+    ctx.synchronize()
+    patterns_create_ms = (time.perf_counter() - t_create) * 1e3
+    bs = ps.build_stats()
     engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
     max_hits = max(1 << 20, 16 * n_pat)
     # fused gather buffer: row 0 = [count, 0], rows 1.. = records; same fixed size on every rank
@@ -525,7 +584,15 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
             gathered = sdist.gatherv_hits(hit_buf[1:1 + min(n, cap)])
         return h, gathered
 
-    for _ in range(args.warmup):
+    # the first scan of a fresh needle set (cold buffers, nothing learnt about the text yet): what a one-shot
+    # `matcher(haystack, callback)` waits for
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    h, g = step()
+    torch.cuda.synchronize()
+    first_scan_ms = (time.perf_counter() - t_first) * 1e3
+    h.close()
+    for _ in range(max(args.warmup - 1, 0)):
         h, g = step()
         h.close()
 
@@ -618,6 +685,12 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         "hits": int(len(hits)),
         "needles_found": int(len(found)),
         "all_planted_found": bool(len(found) == n_pat),
+        "patterns_create_ms": patterns_create_ms,
+        "patterns_create": {"ms_in_the_library": bs.ms_total, "ms_tables": bs.ms_tables, "ms_index": bs.ms_index,
+                            "ms_upload": bs.ms_upload, "host_threads": int(bs.threads), "filter_passes": int(bs.passes),
+                            "dense_pass": bool(bs.dense), "keys": int(bs.keys),
+                            "anchor_sixteenths": int(bs.anchor_sixteenths), "stride": int(bs.stride)},
+        "first_scan_ms": first_scan_ms,
         "verify_ms_per_step": ms_verify / args.steps,
         "candidates": int(st.n_candidates),
         "bands_verified": int(st.n_bands),

@@ -37,7 +37,8 @@ enum spm_status {
     SPM_E_HIP = -2,         /* HIP runtime error (message has the hipError string) */
     SPM_E_NOMEM = -3,
     SPM_E_UNSUPPORTED = -4, /* e.g. needle longer than SPM_MAX_NEEDLE */
-    SPM_E_OVERFLOW = -5     /* hit buffer too small; see spm_scan_opts.max_hits */
+    SPM_E_OVERFLOW = -5,    /* hit buffer too small; see spm_scan_opts.max_hits */
+    SPM_E_PEER = -6         /* multi-GPU exchange: another rank reported an error; nothing was sent or received */
 };
 
 /* Which reference matcher a pattern set stands for. */
@@ -305,6 +306,14 @@ int spm_hip_gatherv_jst_hits(spm_comm *comm, spm_jst_hits *local, int root, cons
                              uint64_t *n_total, uint64_t *counts);
 /* host arithmetic of the gatherv: byte offset of every rank's records in the root's buffer, offsets[world] = total */
 int spm_hip_gatherv_plan(const uint64_t *counts, uint32_t world, uint32_t record_bytes, uint64_t *offsets);
+/* Failure is collective: a rank whose local result is unusable (e.g. SPM_E_OVERFLOW of its scan), a root that cannot hold
+ * the records, counts that overflow the offsets -- all ranks learn of it in an exchange every rank takes part in and return
+ * an error (the failing rank its own, the others SPM_E_PEER) BEFORE any send or receive is posted; nobody is left waiting.
+ * Host-only self-check of that protocol over an in-process loopback of `world` threads (no GPU, no RCCL): scenario 0 clean,
+ * 1 rank `victim` has a local error, 2 the root cannot reserve its buffer, 3 the counts overflow, 4 no rank has records.
+ * detail[world] (may be NULL) receives the status every rank returned.  SPM_OK iff all ranks behaved as promised and
+ * nothing hung. */
+int spm_hip_comm_selftest(int world, int root, int scenario, int victim, uint32_t record_bytes, uint64_t seed, int *detail);
 
 /* ---- synthetic needles of the benchmark configs (host side) -------------------------- */
 uint64_t spm_hip_synth_pattern(uint64_t seed_text, uint64_t seed_pat, uint64_t n_total, uint32_t p, uint32_t L,

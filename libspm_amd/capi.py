@@ -184,6 +184,7 @@ def lib():
         "spm_hip_gatherv_jst_hits": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_uint64)]),
         "spm_hip_gatherv_plan": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "spm_hip_comm_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_int)]),
         "spm_hip_jst_synth_variants": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                                  C.POINTER(JstAllele), C.POINTER(C.c_uint64), u8p,
                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -209,5 +210,5 @@ EXPORTS = [
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",
     "spm_hip_jst_hits_copy_device", "spm_hip_jst_hits_destroy", "spm_hip_jst_synth_variants",
     "spm_hip_comm_unique_id", "spm_hip_comm_init", "spm_hip_comm_destroy", "spm_hip_gatherv_hits",
-    "spm_hip_gatherv_jst_hits", "spm_hip_gatherv_plan",
+    "spm_hip_gatherv_jst_hits", "spm_hip_gatherv_plan", "spm_hip_comm_selftest",
 ]

@@ -11,6 +11,9 @@
 
 #include <dlfcn.h>
 
+#include <mutex>
+
+#include "comm_protocol.hpp"
 #include "common.hpp"
 
 namespace spm_hip
@@ -43,17 +46,25 @@ struct rccl_api
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+inline std::string &rccl_load_error()
+{
+    static std::string e;
+    return e;
+}
+
 inline rccl_api *rccl()
 {
     static rccl_api api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once; // (two threads making their first communicators at the same time load the table once)
+    std::call_once(once, []() {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
             api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (api.lib)
                 break;
+            const char *e = dlerror(); // (read once: the call clears it)
+            if (e)
+                rccl_load_error() = e;
         }
         if (api.lib) {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
@@ -69,9 +80,10 @@ inline rccl_api *rccl()
                 !api.GroupStart || !api.GroupEnd) {
                 dlclose(api.lib);
                 api.lib = nullptr;
+                rccl_load_error() = "symbols missing";
             }
         }
-    }
+    });
     return api.lib ? &api : nullptr;
 }
 
@@ -101,17 +113,13 @@ struct spm_comm
 // Offsets of the gatherv: rank r's records land at byte offsets[r] of the root's buffer; offsets[world] = total bytes.
 extern "C" int spm_hip_gatherv_plan(const uint64_t *counts, uint32_t world, uint32_t record_bytes, uint64_t *offsets)
 {
-    if (!counts || !offsets || world == 0 || record_bytes == 0)
-        return SPM_E_INVALID;
-    uint64_t at = 0;
-    for (uint32_t r = 0; r < world; ++r) {
-        offsets[r] = at;
-        if (counts[r] > (~0ull - at) / record_bytes)
-            return SPM_E_OVERFLOW;
-        at += counts[r] * record_bytes;
-    }
-    offsets[world] = at;
-    return SPM_OK;
+    return spm_hip::gatherv_plan(counts, world, record_bytes, offsets);
+}
+
+extern "C" int spm_hip_comm_selftest(int world, int root, int scenario, int victim, uint32_t record_bytes, uint64_t seed,
+                                     int *detail)
+{
+    return spm_hip::comm_selftest(world, root, scenario, victim, record_bytes, seed, detail);
 }
 
 extern "C" int spm_hip_comm_unique_id(void *id128)
@@ -122,6 +130,8 @@ extern "C" int spm_hip_comm_unique_id(void *id128)
     return A->GetUniqueId(static_cast<spm_hip::rccl_unique_id *>(id128)) == spm_hip::kNcclSuccess ? SPM_OK : SPM_E_HIP;
 }
 
+extern "C" void spm_hip_comm_destroy(spm_comm *c);
+
 extern "C" int spm_hip_comm_init(spm_ctx *ctx, const void *unique_id128, int rank, int world, spm_comm **out)
 {
     if (!ctx || !unique_id128 || !out || world < 1 || rank < 0 || rank >= world) {
@@ -130,11 +140,12 @@ extern "C" int spm_hip_comm_init(spm_ctx *ctx, const void *unique_id128, int ran
     }
     spm_hip::rccl_api *A = spm_hip::rccl();
     if (!A) {
-        SPM_SET_ERR(ctx, "spm_hip_comm_init: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+        SPM_SET_ERR(ctx, "spm_hip_comm_init: librccl.so could not be loaded (%s)", spm_hip::rccl_load_error().c_str());
         return SPM_E_UNSUPPORTED;
     }
     SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    std::unique_ptr<spm_comm> C(new spm_comm);
+    // (the error paths below release the RCCL communicator and the buffers too)
+    std::unique_ptr<spm_comm, void (*)(spm_comm *)> C(new spm_comm, spm_hip_comm_destroy);
     C->ctx = ctx;
     C->rank = rank;
     C->world = world;
@@ -152,8 +163,10 @@ extern "C" void spm_hip_comm_destroy(spm_comm *c)
     if (!c)
         return;
     spm_hip::rccl_api *A = spm_hip::rccl();
-    if (c->ctx)
+    if (c->ctx) {
+        hipSetDevice(c->ctx->device);
         hipStreamSynchronize(c->ctx->stream);
+    }
     if (A && c->comm)
         A->CommDestroy(c->comm);
     hipFree(c->d_counts);
@@ -163,68 +176,95 @@ extern "C" void spm_hip_comm_destroy(spm_comm *c)
     delete c;
 }
 
+namespace
+{
+// the transport of comm_protocol.hpp over RCCL + HIP, on the context's stream
+struct rccl_transport : spm_hip::gatherv_transport
+{
+    spm_comm *c;
+    spm_hip::rccl_api *A;
+    explicit rccl_transport(spm_comm *comm) : c(comm), A(spm_hip::rccl()) {}
+    int exchange_words(uint64_t mine, uint64_t *all) override
+    {
+        spm_ctx *ctx = c->ctx;
+        const int W = c->world;
+        c->h_counts[W] = mine;
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c->d_counts + W, c->h_counts + W, sizeof(unsigned long long), hipMemcpyHostToDevice,
+                                          ctx->stream));
+        SPM_RCCL_CHECK(ctx, A->AllGather(c->d_counts + W, c->d_counts, 1, spm_hip::kNcclUint64, c->comm, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                          ctx->stream));
+        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < W; ++r)
+            all[r] = c->h_counts[r];
+        return SPM_OK;
+    }
+    int reserve(uint64_t bytes, void **buffer) override
+    {
+        spm_ctx *ctx = c->ctx;
+        if (bytes > c->recv_bytes) {
+            hipFree(c->d_recv);
+            c->d_recv = nullptr;
+            c->recv_bytes = 0;
+            const uint64_t want = bytes + bytes / 4 + 4096;
+            if (hipMalloc(&c->d_recv, want) != hipSuccess) {
+                c->d_recv = nullptr;
+                SPM_SET_ERR(ctx, "gatherv: the root cannot allocate %llu bytes for the gathered records", (unsigned long long)want);
+                return SPM_E_NOMEM;
+            }
+            c->recv_bytes = want;
+        }
+        *buffer = c->d_recv;
+        return SPM_OK;
+    }
+    int copy_own(void *dst, const void *src, uint64_t bytes) override
+    {
+        SPM_HIP_CHECK(c->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->ctx->stream));
+        return SPM_OK;
+    }
+    int group_begin() override
+    {
+        SPM_RCCL_CHECK(c->ctx, A->GroupStart());
+        return SPM_OK;
+    }
+    int send(const void *src, uint64_t bytes, int peer) override
+    {
+        SPM_RCCL_CHECK(c->ctx, A->Send(src, bytes, spm_hip::kNcclUint8, peer, c->comm, c->ctx->stream));
+        return SPM_OK;
+    }
+    int recv(void *dst, uint64_t bytes, int peer) override
+    {
+        SPM_RCCL_CHECK(c->ctx, A->Recv(dst, bytes, spm_hip::kNcclUint8, peer, c->comm, c->ctx->stream));
+        return SPM_OK;
+    }
+    int group_end() override
+    {
+        SPM_RCCL_CHECK(c->ctx, A->GroupEnd());
+        return SPM_OK;
+    }
+    int finish() override
+    {
+        SPM_HIP_CHECK(c->ctx, hipStreamSynchronize(c->ctx->stream));
+        return SPM_OK;
+    }
+};
+} // namespace
+
 // Gather `n_local` records of `record_bytes` bytes (device memory) from every rank to `root`, rank order = shard order.
 // On the root: *device_records = the gathered records (owned by the communicator, valid until the next call),
 // counts[0..world) = records per rank (may be NULL), *n_total = their sum.  Elsewhere *device_records = NULL, *n_total = 0.
-// Runs on the context's stream; returns when the records are there (one host synchronisation: the root has to size its
-// receives).
-static int gatherv_device(spm_comm *c, const void *d_local, uint64_t n_local, uint32_t record_bytes, int root,
+// local_error: this rank's result is unusable -- it still takes part, and every rank returns an error (comm_protocol.hpp).
+// Runs on the context's stream; returns when the records are there.
+static int gatherv_device(spm_comm *c, int local_error, const void *d_local, uint64_t n_local, uint32_t record_bytes, int root,
                           const void **device_records, uint64_t *n_total, uint64_t *counts)
 {
-    spm_ctx *ctx = c->ctx;
-    spm_hip::rccl_api *A = spm_hip::rccl();
-    SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const int W = c->world;
-    c->h_counts[W] = n_local;
-    SPM_HIP_CHECK(ctx, hipMemcpyAsync(c->d_counts + W, c->h_counts + W, sizeof(unsigned long long), hipMemcpyHostToDevice,
-                                      ctx->stream));
-    SPM_RCCL_CHECK(ctx, A->AllGather(c->d_counts + W, c->d_counts, 1, spm_hip::kNcclUint64, c->comm, ctx->stream));
-    *device_records = nullptr;
-    *n_total = 0;
-    if (c->rank != root) {
-        if (n_local) {
-            SPM_RCCL_CHECK(ctx, A->GroupStart());
-            SPM_RCCL_CHECK(ctx, A->Send(d_local, n_local * record_bytes, spm_hip::kNcclUint8, root, c->comm, ctx->stream));
-            SPM_RCCL_CHECK(ctx, A->GroupEnd());
-        }
-        SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        return SPM_OK;
-    }
-    SPM_HIP_CHECK(ctx, hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                      ctx->stream));
-    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint64_t> cnt(c->h_counts, c->h_counts + W), off((size_t)W + 1);
-    int rc = spm_hip_gatherv_plan(cnt.data(), (uint32_t)W, record_bytes, off.data());
-    if (rc != SPM_OK)
-        return rc;
-    if (off[W] > c->recv_bytes) {
-        hipFree(c->d_recv);
-        c->d_recv = nullptr;
-        c->recv_bytes = 0;
-        SPM_HIP_CHECK(ctx, hipMalloc(&c->d_recv, off[W] + off[W] / 4 + 4096));
-        c->recv_bytes = off[W] + off[W] / 4 + 4096;
-    }
-    if (cnt[root])
-        SPM_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)c->d_recv + off[root], d_local, cnt[root] * record_bytes,
-                                          hipMemcpyDeviceToDevice, ctx->stream));
-    bool any = false;
-    for (int r = 0; r < W; ++r)
-        any = any || (r != root && cnt[r]);
-    if (any) {
-        SPM_RCCL_CHECK(ctx, A->GroupStart());
-        for (int r = 0; r < W; ++r)
-            if (r != root && cnt[r])
-                SPM_RCCL_CHECK(ctx, A->Recv((uint8_t *)c->d_recv + off[r], cnt[r] * record_bytes, spm_hip::kNcclUint8, r,
-                                            c->comm, ctx->stream));
-        SPM_RCCL_CHECK(ctx, A->GroupEnd());
-    }
-    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    *device_records = c->d_recv;
-    *n_total = off[W] / record_bytes;
-    if (counts)
-        for (int r = 0; r < W; ++r)
-            counts[r] = cnt[r];
-    return SPM_OK;
+    SPM_HIP_CHECK(c->ctx, hipSetDevice(c->ctx->device));
+    rccl_transport T(c);
+    const int rc = spm_hip::gatherv_protocol(T, c->rank, c->world, root, local_error, d_local, n_local, record_bytes,
+                                             device_records, n_total, counts);
+    if (rc == SPM_E_PEER)
+        SPM_SET_ERR(c->ctx, "gatherv: another rank reported an error; nothing was exchanged");
+    return rc;
 }
 
 extern "C" int spm_hip_gatherv_hits(spm_comm *c, spm_hits *local, int root, const void **device_records,
@@ -237,10 +277,8 @@ extern "C" int spm_hip_gatherv_hits(spm_comm *c, spm_hits *local, int root, cons
     }
     const void *d = nullptr;
     uint64_t n = 0;
-    int rc = spm_hip_hits_device(local, &d, &n);
-    if (rc != SPM_OK)
-        return rc;
-    return gatherv_device(c, d, n, (uint32_t)sizeof(spm_hit), root, device_records, n_total, counts);
+    const int rc = spm_hip_hits_device(local, &d, &n); // (e.g. SPM_E_OVERFLOW: more hits than max_hits -- told to every rank)
+    return gatherv_device(c, rc, d, rc == SPM_OK ? n : 0, (uint32_t)sizeof(spm_hit), root, device_records, n_total, counts);
 }
 
 extern "C" int spm_hip_gatherv_jst_hits(spm_comm *c, spm_jst_hits *local, int root, const void **device_records,
@@ -253,8 +291,6 @@ extern "C" int spm_hip_gatherv_jst_hits(spm_comm *c, spm_jst_hits *local, int ro
     }
     const void *d = nullptr;
     uint64_t n = 0;
-    int rc = spm_hip_jst_hits_device(local, &d, &n);
-    if (rc != SPM_OK)
-        return rc;
-    return gatherv_device(c, d, n, (uint32_t)sizeof(spm_jst_hit), root, device_records, n_total, counts);
+    const int rc = spm_hip_jst_hits_device(local, &d, &n);
+    return gatherv_device(c, rc, d, rc == SPM_OK ? n : 0, (uint32_t)sizeof(spm_jst_hit), root, device_records, n_total, counts);
 }

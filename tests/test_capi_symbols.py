@@ -73,3 +73,28 @@ def test_gatherv_plan_offsets(spm):
     huge = np.array([1 << 62, 1 << 62], dtype=np.uint64)
     assert L.spm_hip_gatherv_plan(huge.ctypes.data_as(u64p), 2, 16, offs.ctypes.data_as(u64p)) == -5   # SPM_E_OVERFLOW
     assert L.spm_hip_gatherv_plan(None, 2, 16, offs.ctypes.data_as(u64p)) == -1
+
+
+def test_native_gatherv_protocol_never_leaves_a_rank_waiting(spm):
+    """The native RCCL gatherv (csrc/comm.hpp) as a protocol over an in-process loopback of `world` threads
+    (csrc/comm_protocol.hpp, spm_hip_comm_selftest): the root holds every rank's records at the planned offsets; a rank
+    with a local error (its scan overflowed), a root that cannot allocate, counts that overflow the offsets -- every rank
+    returns an error (the failing one its own, the others SPM_E_PEER) before any send or receive is posted; nothing hangs."""
+    L = spm.capi.lib()
+    OK, NOMEM, OVERFLOW, PEER = 0, -3, -5, -6
+    for world in (1, 2, 3, 4, 8):
+        for root in sorted({0, world - 1}):
+            for rec in (16, 24):   # spm_hit / spm_jst_hit
+                d = (ctypes.c_int * world)()
+                assert L.spm_hip_comm_selftest(world, root, 0, 0, rec, 1234 + world, d) == OK and list(d) == [OK] * world
+                assert L.spm_hip_comm_selftest(world, root, 4, 0, rec, 1, d) == OK and list(d) == [OK] * world   # nobody has records
+            for victim in sorted({0, world // 2, world - 1}):
+                d = (ctypes.c_int * world)()
+                assert L.spm_hip_comm_selftest(world, root, 1, victim, 16, 99, d) == OK
+                assert list(d) == [OVERFLOW if r == victim else PEER for r in range(world)]
+            d = (ctypes.c_int * world)()
+            assert L.spm_hip_comm_selftest(world, root, 2, 0, 16, 7, d) == OK
+            assert list(d) == [NOMEM if r == root else PEER for r in range(world)]
+            if world > 1:
+                assert L.spm_hip_comm_selftest(world, root, 3, 0, 16, 7, d) == OK and list(d) == [OVERFLOW] * world
+    assert L.spm_hip_comm_selftest(0, 0, 0, 0, 16, 1, None) == -1
