@@ -534,9 +534,9 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         n_pat = args.needles
     per_gpu = int(gib * 2**30) & ~1023
     n_total = per_gpu * world
-    lo, hi = sdist.shard_range(n_total, rank, world)
     window = L + kmax
-    ovl = 0 if lo == 0 else 1024  # >= window_size-1 symbols of left context, keeps the shard 1 KiB aligned
+    sp = sdist.ShardPlan(n_total, rank, world, window)   # owned range, left context, global coordinates (tests/test_dist_gloo.py)
+    lo, hi, ovl = sp.lo, sp.hi, sp.ovl
     repeats = workload == "c3r"
     rep_ppm = int(round(args.repeat_frac * 1e6)) if repeats else 0
 
@@ -559,30 +559,19 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     patterns_create_ms = (time.perf_counter() - t_create) * 1e3
     bs = ps.build_stats()
     engine = {"auto": S.ENGINE_AUTO, "brute": S.ENGINE_BRUTE, "filter": S.ENGINE_FILTER}[args.engine]
-    max_hits = max(1 << 20, 16 * n_pat)
-    # fused gather buffer: row 0 = [count, 0], rows 1.. = records; same fixed size on every rank
-    cap = 1 << 12   # small on purpose: the all-gather moves world x (cap + 1) x 16 bytes per step
-    while cap < 8 * n_pat:
-        cap <<= 1
-    if repeats:
-        # a needle that lies inside a repeat stretch matches every long stretch of the same unit: millions of hits
-        max_hits = 1 << 26
-        cap = max_hits
-    hit_buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
-    # few records (C2, C3: <= 128 KB per rank): one fused all-gather of fixed-size buffers, no count exchange;
-    # many (C4: ~51 000 hits per rank, c3r: millions): the count-then-send gatherv moves what there is, not the capacity
-    fused = cap <= (1 << 13)
+    # how the records travel: one fused all-gather of fixed-size buffers (C2, C3) or count + send/recv (C4, c3r)
+    xp = sdist.ExchangePlan(n_pat, many_hits=repeats)
+    max_hits, cap, fused = xp.max_hits, xp.cap, xp.fused
+    hit_buf = xp.new_buffer(dev)
 
     def step():
-        h = S.scan(ctx, text, ps, ovl, ovl + (hi - lo), engine=engine, left_context=True,
-                   pos_offset=lo - ovl, max_hits=max_hits)
+        h = S.scan(ctx, text, ps, sp.scan_begin, sp.scan_end, engine=engine, left_context=True,
+                   pos_offset=sp.pos_offset, max_hits=max_hits)
         if fused:
             n = h.copy_fused(hit_buf.data_ptr(), cap)        # [count | records], on the scan's stream
-            gathered = sdist.gather_hits_fused(hit_buf)      # N > 1: one ncclAllGather; N = 1: a view
         else:
             n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
-            gathered = sdist.gatherv_hits(hit_buf[1:1 + min(n, cap)])
-        return h, gathered
+        return h, xp.exchange(hit_buf, n)                    # N > 1: the collective; N = 1: a view
 
     # the first scan of a fresh needle set (cold buffers, nothing learnt about the text yet): what a one-shot
     # `matcher(haystack, callback)` waits for
@@ -623,7 +612,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     st, gathered = last
     if rank != 0:
         return None
-    recs = (sdist.split_fused(gathered) if fused else gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
+    recs = xp.records(gathered).cpu().numpy().view(np.uint8).reshape(-1, 16)
     hits = np.frombuffer(recs.tobytes(), dtype=S.HIT_DTYPE)
     found = np.unique(hits["pattern"])
     ms_per_step = dt / args.steps * 1e3

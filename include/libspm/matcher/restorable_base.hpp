@@ -105,7 +105,9 @@ public:
 
     state_type const & capture() const noexcept
     {
-        if (_replay_text == nullptr)
+        // outside a callback, or right after restore() inside one: the live state -- what the reference's capture()
+        // returns, its pattern state being the restored one from that point on (myers_matcher_restorable.hpp:55-61)
+        if (_replay_text == nullptr || _restore_pending)
             return _state;
         // inside a callback: the state right after the hit's last symbol, continued from the previous capture
         if (_replay_end > _cap_pos) {

@@ -51,7 +51,9 @@ struct spm_ctx
     uint64_t band_slots = 0;
     bool band_dirty = false;
     unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs
-                                              // an extra staging hop on every scan)
+                                              // an extra staging hop on every scan); [13], [14]: header of hits_copy_fused
+    hipEvent_t fused_hdr_ev = nullptr;        // recorded behind the last header copy out of h_counters[13..14]
+    bool fused_hdr_pending = false;
 };
 
 struct spm_text

@@ -966,6 +966,11 @@ extern "C" int spm_hip_jst_index(spm_jst *J, uint32_t window, uint32_t block_len
     J->stats.window = window;
     J->stats.ms_index = ms;
     J->indexed = true;
+    if (spm_trace_on())
+        fprintf(stderr, "[spm_hip] jst_index: window %u, %llu blocks of %u: %llu contexts, %llu unique, %llu symbols laid out "
+                        "for %llu haplotype symbols; %.3f ms\n", window, (unsigned long long)nb, (unsigned)L,
+                (unsigned long long)totals[0], (unsigned long long)n_ctx, (unsigned long long)ctx_bytes,
+                (unsigned long long)totals[1], ms);
     return SPM_OK;
 }
 
@@ -1128,6 +1133,10 @@ extern "C" int spm_hip_jst_search(spm_jst *J, const spm_patterns *patterns, cons
         return SPM_E_OVERFLOW;
     }
     R->n = n_out;
+    if (spm_trace_on())
+        fprintf(stderr, "[spm_hip] jst_search: %llu segment hits -> %llu records; scan %.3f ms (main %.3f, verification %.3f), "
+                        "fan-out %.3f ms%s\n", (unsigned long long)n_seg_hits, n_out, J->stats.ms_scan, J->stats.ms_main,
+                J->stats.ms_verify, J->stats.ms_fanout, J->stats.fell_back ? "; the seed filter fell back" : "");
     *out = R.release();
     return SPM_OK;
 }

@@ -445,6 +445,8 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
         hipFree(b.first);
     if (ctx->h_counters)
         hipHostFree(ctx->h_counters);
+    if (ctx->fused_hdr_ev)
+        hipEventDestroy(ctx->fused_hdr_ev);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
@@ -1487,6 +1489,7 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
     spm_scan_opts opts{};
     if (opts_in)
         opts = *opts_in;
+    const auto t_call = clk::now();
     SPM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 
     std::unique_ptr<spm_hits, void (*)(spm_hits *)> H(new spm_hits, spm_hip_hits_destroy);
@@ -1795,6 +1798,17 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             hipFree(d_in);
         }
     }
+    if (spm_trace_on()) { // (costs one event synchronisation: diagnostics only)
+        spm_scan_stats st{};
+        spm_hip_hits_stats(H.get(), &st);
+        fprintf(stderr, "[spm_hip] scan [%llu, %llu)%s: engine %s%s, %u main launch(es); %.3f ms (main %.3f, verification %.3f); "
+                        "%llu seed-checked pairs, %u bands, %llu hits%s; host %.3f ms\n",
+                (unsigned long long)begin, (unsigned long long)end, seg_offsets || d_seg_offsets ? " segmented" : "",
+                st.engine_used == SPM_ENGINE_FILTER ? (patterns->filter_dense ? "filter (dense pass)" : "filter") : "brute",
+                st.fell_back ? " after a whole-scan fallback" : "", st.main_launches, st.ms_total, st.ms_main, st.ms_verify,
+                (unsigned long long)st.n_candidates, st.n_bands, (unsigned long long)st.n_hits,
+                st.fallback_spans ? " (spans re-scanned by the brute-force kernel)" : "", ms_since(t_call));
+    }
     *out = H.release();
     return SPM_OK;
 }
@@ -1881,9 +1895,22 @@ extern "C" int spm_hip_hits_copy_fused(spm_hits *h, void *device_dst, uint64_t c
     if (rc != SPM_OK)
         return rc;
     *n = h->n;
-    // header: the count (16 bytes from pageable memory: staged by the runtime before the call returns)
-    const unsigned long long hdr[2] = {h->n, 0};
-    SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(device_dst, hdr, 16, hipMemcpyHostToDevice, h->ctx->stream));
+    // header: the count, from memory that outlives the call (the context's pinned block: slots 13 / 14 belong to nobody
+    // else; an asynchronous copy from a stack array reads a dead frame if the runtime does not stage it first).  The
+    // stream orders this copy behind the previous call's, so the slots are free to overwrite once that copy was issued
+    // -- which a host that reuses them needs a fence for: wait for the last header copy before writing the next.
+    spm_ctx *ctx = h->ctx;
+    if (ctx->fused_hdr_ev) {
+        if (ctx->fused_hdr_pending)
+            SPM_HIP_CHECK(ctx, hipEventSynchronize(ctx->fused_hdr_ev));
+    } else {
+        SPM_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->fused_hdr_ev, hipEventDisableTiming));
+    }
+    ctx->h_counters[13] = h->n;
+    ctx->h_counters[14] = 0;
+    SPM_HIP_CHECK(ctx, hipMemcpyAsync(device_dst, ctx->h_counters + 13, 16, hipMemcpyHostToDevice, ctx->stream));
+    SPM_HIP_CHECK(ctx, hipEventRecord(ctx->fused_hdr_ev, ctx->stream));
+    ctx->fused_hdr_pending = true;
     const uint64_t c = std::min(h->n, cap);
     if (c)
         SPM_HIP_CHECK(h->ctx, hipMemcpyAsync(static_cast<uint8_t *>(device_dst) + sizeof(spm_hit), h->d_hits, c * sizeof(spm_hit),

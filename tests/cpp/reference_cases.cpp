@@ -402,6 +402,22 @@ static void paused_scan_cases()
         b(part2, [&](auto const & f) { two.push_back(seqan2::endPosition(f) + 14); });
         EXPECT_TRUE(std::ranges::equal(got, two));
     }
+    { // restore() then capture() inside ONE callback: capture returns the live pattern state, i.e. the restored one
+      // (myers_matcher_restorable.hpp:55-61), not the state at the hit
+        auto matcher = get_matcher();
+        auto const fresh = spm::capture(matcher);
+        int seen = 0;
+        bool same_as_restored = false, differs_before = false;
+        matcher(haystack, [&](auto const &) {
+            if (++seen == 2) {
+                differs_before = !(spm::capture(matcher) == fresh); // (the state at the 2nd hit has read 14 symbols)
+                spm::restore(matcher, fresh);
+                same_as_restored = spm::capture(matcher) == fresh;
+            }
+        });
+        EXPECT_TRUE(differs_before);
+        EXPECT_TRUE(same_as_restored);
+    }
     { // more hits than the default device hit buffer (2^20): |P| = 5, k = 1 on 3 Mbases of ACGT..: no limit, no abort
         std::size_t const n = 3u << 20;
         sequence_t big(n);
