@@ -2056,7 +2056,11 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 // instead of 32 blocks x 13 on a single lane, so the latency of one verification drops from ~1.5 ms to ~0.1 ms --
 // what matters when a scan leaves a few hundred long bands to verify.  Reads the bottom-aligned table of the cut-off
 // kernel ([group][row][nw_table][64]); each lane keeps the <= 5 match masks of its block in registers.
-template <int G>
+// NB: 32-row blocks per lane.  A scan leaves a few thousand long bands; with one block per lane a |P| = 1024 band takes 32
+// lanes, a wave holds two bands, and 2 800 bands are 1 400 busy waves on 1 024 SIMDs: the SIMDs that got two of them run
+// every step twice, and they set the kernel's duration.  Two blocks per lane (the second takes the first one's hout in the
+// same step) put four bands into a wave -- 700 busy waves, at most one per SIMD -- at ~1.7x the instructions of a step.
+template <int G, int NB>
 __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P, const uint32_t *__restrict__ peq_bot)
 {
     // per group of G lanes: [2*max_k + 1 + max_span] uint16 hit slots, then the candidate's text window (wave_text bytes)
@@ -2108,11 +2112,16 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             band_release(P.band_tab, c.slot);
         if (active && gl == 0)
             ++n_valid;
-        const uint32_t nb = (uint32_t)((m + 31) >> 5);        // blocks of this needle
-        const bool is_last = gl + 1 == nb;
-        const uint32_t out_bit = is_last ? (uint32_t)((m - 1) & 31) : 31u; // where this block's hout is read
+        const uint32_t nbk = (uint32_t)((m + 31) >> 5);       // blocks of this needle
+        const uint32_t nb = (nbk + NB - 1) / NB;              // lanes that hold them
         const uint32_t n_cols = active ? (uint32_t)(e_hi - ws) : 0u;
         const bool mine = active && gl < nb;
+        const bool lane_last = gl + 1 == nb;                  // holds the needle's last block, at index j_last
+        const uint32_t j_last = (nbk - 1) % NB;
+        uint32_t out_bit[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            out_bit[j] = (gl * NB + (uint32_t)j + 1 == nbk) ? (uint32_t)((m - 1) & 31) : 31u; // where block j's hout is read
         // ---- stage the text window [ws, e_hi) into LDS: 16-byte blocks, the group's lanes side by side ----
         const uint32_t skew = (uint32_t)(ws & 15);
         uint32_t beyond4 = 0; // a byte >= 4 somewhere in the window (never in a validated dna4 text)
@@ -2125,19 +2134,29 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
             }
         }
         const bool plain4 = P.sigma == 4 && __ballot(beyond4 != 0) == 0; // (wave-uniform) every symbol selects a match mask
-        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
-        if (mine) {
-            const uint32_t *src = peq_bot + (((size_t)(pat >> 6) * rows) * P.nw_table + gl) * 64 + (pat & 63);
-            const size_t rs = (size_t)P.nw_table * 64;
-            e0 = src[0];
-            e1 = src[rs];
-            e2 = P.sigma > 2 ? src[2 * rs] : 0u;
-            e3 = P.sigma > 3 ? src[3 * rs] : 0u;
-            e4 = P.sigma > 4 ? src[4 * rs] : 0u;
+        uint32_t e0[NB], e1[NB], e2[NB], e3[NB], e4[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            e0[j] = e1[j] = e2[j] = e3[j] = e4[j] = 0;
+            const uint32_t gb = gl * NB + (uint32_t)j; // (a block beyond the needle matches nothing)
+            if (mine && gb < nbk) {
+                const uint32_t *src = peq_bot + (((size_t)(pat >> 6) * rows) * P.nw_table + gb) * 64 + (pat & 63);
+                const size_t rs = (size_t)P.nw_table * 64;
+                e0[j] = src[0];
+                e1[j] = src[rs];
+                e2[j] = P.sigma > 2 ? src[2 * rs] : 0u;
+                e3[j] = P.sigma > 3 ? src[3 * rs] : 0u;
+                e4[j] = P.sigma > 4 ? src[4 * rs] : 0u;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t Pv = 0xFFFFFFFFu, Mv = 0, ho = 0;
+        uint32_t Pv[NB], Mv[NB], ho = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            Pv[j] = 0xFFFFFFFFu;
+            Mv[j] = 0;
+        }
         int32_t score = (int32_t)m;
         bool any_hit = false;
         const uint32_t first_slot_col = (uint32_t)(e_lo - ws) - 1; // column whose end position is e_lo
@@ -2163,14 +2182,14 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
         t_lo = t_lo > t_hi ? t_hi : t_lo;
         t_hit = t_hit < t_lo ? t_lo : (t_hit > t_hi ? t_hi : t_hit);
         uint32_t sym_next = mine ? tw[skew] : 0u; // column 0 (clamped reads below keep every index inside the window)
-        // One step of one block.  CHECKED: the lane may have no column at this step (the pipeline fills and drains, or a
-        // shorter band shares the wave).  The steps in between -- nearly all -- run without exec-mask changes and with
-        // the match mask picked by bit selects instead of compare / cndmask chains: a band is a serial chain of ~1400
-        // steps, one wave per SIMD, so the scan pays for every instruction and every VALU -> SALU hand-over of a step.
+        // One step of one lane's blocks.  CHECKED: the lane may have no column at this step (the pipeline fills and drains,
+        // or a shorter band shares the wave).  The steps in between -- nearly all -- run without exec-mask changes and with
+        // the match mask picked by bit selects instead of compare / cndmask chains: a band is a serial chain of ~1500
+        // steps, so the scan pays for every instruction and every VALU -> SALU hand-over of a step.
         // (unchecked steps: a lane that holds a block reads its own column, any other lane anything inside its group's LDS;
         // only the lane of the last block can meet score <= k_hit)
         const uint8_t *my_text = mine ? tw + skew - gl : tw;
-        const int32_t k_hit = (is_last && mine) ? (int32_t)k : -1;
+        const int32_t k_hit = (lane_last && mine) ? (int32_t)k : -1;
         const uint32_t n_rel = n_cols - first_slot_col; // end-position slots of this band
         auto step = [&](uint32_t t, auto checked, auto dna4, auto hits) {
             const uint32_t ho_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ho, 0x138, 0xF, 0xF, false);
@@ -2184,31 +2203,42 @@ __global__ __launch_bounds__(256) void verify_wave_kernel(const verify_params P,
                 sym_next = my_text[t + 1];
             }
             if (!decltype(checked)::value || (mine && col < n_cols)) {
-                uint32_t Eq;
+                uint32_t hin = gl == 0 ? 0u : ho_up;
+                uint32_t s0 = 0, s1 = 0;
                 if constexpr (decltype(dna4)::value) {
-                    const uint32_t s0 = (uint32_t)((int32_t)(sym << 31) >> 31), s1 = (uint32_t)((int32_t)(sym << 30) >> 31);
-                    const uint32_t lo2 = (e1 & s0) | (e0 & ~s0), hi2 = (e3 & s0) | (e2 & ~s0);
-                    Eq = (hi2 & s1) | (lo2 & ~s1); // (plain4: no symbol beyond 3 in the window)
-                } else {
-                    const uint32_t lo2 = (sym & 1u) ? e1 : e0, hi2 = (sym & 1u) ? e3 : e2;
-                    Eq = (sym & 2u) ? hi2 : lo2;
-                    Eq = sym < 4 ? Eq : (sym == 4 ? e4 : 0u);
-                    Eq = sym < P.sigma ? Eq : 0u;
+                    s0 = (uint32_t)((int32_t)(sym << 31) >> 31);
+                    s1 = (uint32_t)((int32_t)(sym << 30) >> 31);
                 }
-                const uint32_t hin = gl == 0 ? 0u : ho_up;
-                const uint32_t hp = hin & 1u, hn = hin >> 1;
-                const uint32_t Xv = Eq | Mv;
-                Eq |= hn;
-                const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                uint32_t Ph = Mv | ~(Xh | Pv);
-                uint32_t Mh = Pv & Xh;
-                const uint32_t op = (Ph >> out_bit) & 1u, on = (Mh >> out_bit) & 1u;
-                ho = op | (on << 1);
-                Ph = (Ph << 1) | hp;
-                Mh = (Mh << 1) | hn;
-                Pv = Mh | ~(Xv | Ph);
-                Mv = Ph & Xv;
-                score += (int32_t)op - (int32_t)on;
+                int32_t d_last = 0; // op - on of the needle's last block (meaningful on its lane only)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    uint32_t Eq;
+                    if constexpr (decltype(dna4)::value) {
+                        const uint32_t lo2 = (e1[j] & s0) | (e0[j] & ~s0), hi2 = (e3[j] & s0) | (e2[j] & ~s0);
+                        Eq = (hi2 & s1) | (lo2 & ~s1); // (plain4: no symbol beyond 3 in the window)
+                    } else {
+                        const uint32_t lo2 = (sym & 1u) ? e1[j] : e0[j], hi2 = (sym & 1u) ? e3[j] : e2[j];
+                        Eq = (sym & 2u) ? hi2 : lo2;
+                        Eq = sym < 4 ? Eq : (sym == 4 ? e4[j] : 0u);
+                        Eq = sym < P.sigma ? Eq : 0u;
+                    }
+                    const uint32_t hp = hin & 1u, hn = hin >> 1;
+                    const uint32_t Xv = Eq | Mv[j];
+                    Eq |= hn;
+                    const uint32_t Xh = (((Eq & Pv[j]) + Pv[j]) ^ Pv[j]) | Eq;
+                    uint32_t Ph = Mv[j] | ~(Xh | Pv[j]);
+                    uint32_t Mh = Pv[j] & Xh;
+                    const uint32_t op = (Ph >> out_bit[j]) & 1u, on = (Mh >> out_bit[j]) & 1u;
+                    hin = op | (on << 1); // this block's hout: the next block's hin, in this very step
+                    Ph = (Ph << 1) | hp;
+                    Mh = (Mh << 1) | hn;
+                    Pv[j] = Mh | ~(Xv | Ph);
+                    Mv[j] = Ph & Xv;
+                    if (NB == 1 || (uint32_t)j == j_last)
+                        d_last = (int32_t)op - (int32_t)on;
+                }
+                ho = hin;
+                score += d_last;
                 if constexpr (decltype(hits)::value) {
                     const uint32_t rel = col - first_slot_col;
                     if (score <= k_hit && rel < n_rel) {

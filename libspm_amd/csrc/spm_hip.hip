@@ -755,11 +755,11 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((verify_kernel<NWN>), grid, dim3(threads), lds, s, V);
 }
 
-template <int G>
+template <int G, int NB>
 void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid, hipStream_t s)
 {
     // One wave per workgroup: a scan leaves a few thousand long bands, i.e. far fewer busy waves than the GPU has SIMDs,
-    // and each is a serial chain ~1400 steps long.  With four-wave workgroups filled in order, the dispatcher packed the
+    // and each is a serial chain ~1500 steps long.  With four-wave workgroups filled in order, the dispatcher packed the
     // busy waves four to a SIMD on a third of the CUs and left the rest idle.
     const uint32_t threads = (uint32_t)std::max(64, std::min(256, env_int("SPM_HIP_VERIFY_WAVE_THREADS", 64)));
     grid.x *= 256 / threads;
@@ -767,23 +767,36 @@ void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max
     // text window of one candidate: cold start |P| + k symbols before the first end position, then the end positions
     V.wave_text = ((max_m + V.max_k + n_slots + 16 + 15) & ~15u) + 16;
     const size_t per_group = ((n_slots * 2 + 15) & ~15u) + V.wave_text;
-    const size_t lds = (size_t)(threads / 64) * (64 / G) * per_group;
-    hipFuncSetAttribute((const void *)verify_wave_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((verify_wave_kernel<G>), grid, dim3(threads), lds, s, V, peq_bot);
+    size_t lds = (size_t)(threads / 64) * (64 / G) * per_group;
+    // (diagnostics: a larger LDS claim per workgroup caps how many of them a CU takes at once)
+    lds = std::max<size_t>(lds, (size_t)std::max(0, std::min(160, env_int("SPM_HIP_VERIFY_WAVE_LDS_KB", 0))) * 1024);
+    hipFuncSetAttribute((const void *)verify_wave_kernel<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((verify_wave_kernel<G, NB>), grid, dim3(threads), lds, s, V, peq_bot);
 }
 
-// long needles: one lane per 32-row block, G = lanes per candidate >= blocks of the longest needle
+// long needles: NB 32-row blocks per lane, G = lanes per band >= blocks of the longest needle / NB.  SPM_HIP_VERIFY_WAVE_NB=2:
+// two blocks per lane from 17 blocks on (four |P| = 1024 bands share a wave instead of two).
 void launch_verify_wave(uint32_t n_blocks, const verify_params &V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid,
                         hipStream_t s)
 {
+    // (measured on C5, 2 798 bands of |P| = 1024: one block per lane 0.300 ms, two 0.358 -- a step is a chain of dependent
+    // instructions, its latency and not its issue slots set the pace, and the second block lengthens the chain.)
+    const bool two = env_int("SPM_HIP_VERIFY_WAVE_NB", 1) >= 2;
     if (n_blocks <= 8)
-        launch_verify_wave_g<8>(V, peq_bot, max_m, grid, s);
+        launch_verify_wave_g<8, 1>(V, peq_bot, max_m, grid, s);
     else if (n_blocks <= 16)
-        launch_verify_wave_g<16>(V, peq_bot, max_m, grid, s);
-    else if (n_blocks <= 32)
-        launch_verify_wave_g<32>(V, peq_bot, max_m, grid, s);
-    else
-        launch_verify_wave_g<64>(V, peq_bot, max_m, grid, s);
+        launch_verify_wave_g<16, 1>(V, peq_bot, max_m, grid, s);
+    else if (n_blocks <= 32) {
+        if (two)
+            launch_verify_wave_g<16, 2>(V, peq_bot, max_m, grid, s);
+        else
+            launch_verify_wave_g<32, 1>(V, peq_bot, max_m, grid, s);
+    } else {
+        if (two)
+            launch_verify_wave_g<32, 2>(V, peq_bot, max_m, grid, s);
+        else
+            launch_verify_wave_g<64, 1>(V, peq_bot, max_m, grid, s);
+    }
 }
 
 // nwn = 32-bit words that can hold needle rows = ceil(max |P| / 32), rounded up to an instantiated width
@@ -1139,8 +1152,6 @@ int run_filter(const scan_args &A)
     {
         const int sb = env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0);
         P.span_budget = sb > 0 ? (uint32_t)sb : (uint32_t)std::max<uint64_t>(256, span * 1024 / 4);
-        if (A.seg_offsets || A.d_seg_offsets)
-            P.span_budget = 0xFFFFFFFFu; // segmented scans fall back as a whole (tiles would have to follow the segments)
     }
     // span dequeue: per wave while the dequeue rate stays far below what one atomic word sustains (~88/us, i.e.
     // spans >= 192 KiB at 7 TB/s), per workgroup otherwise (measured: C3 2.52 vs 2.59 ms, C2 0.88 vs 0.20 ms)
@@ -1227,7 +1238,7 @@ int run_filter(const scan_args &A)
         pspan = (pspan + 3) & ~3ull;
         Q.span_chunks = (uint32_t)pspan;
         Q.span_unit = 4096;
-        if (env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0) <= 0 && Q.span_budget != 0xFFFFFFFFu)
+        if (env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0) <= 0)
             Q.span_budget = (uint32_t)std::max<uint64_t>(256, pspan * 4096 / 4);
         Q.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (pspan >= 48 ? 1u : 2u);
         const uint4 *shadow = reinterpret_cast<const uint4 *>(A.text->d_packed);
@@ -1592,14 +1603,14 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
                 break;
             // Start over with more room when the lists were too small for this text (the first attempt counted the
             // demand): survivor buffer full -- spans gave up for that reason, not for their own budget --, or band list /
-            // band table / dedupe set full.  Segmented scans have no span budget: their survivor count is exact.
+            // band table / dedupe set full.
             const bool more_surv = c[1] > H->cand_cap && H->cand_cap < (1ull << 27) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0);
             const bool more_bands = c[2] != 0 && c[3] > H->band_cap && H->band_cap < (1ull << 28);
             const bool more_seen = c[2] != 0 && !A.seen_full && !more_bands && c[3] <= H->band_cap;
             if (!more_surv && !more_bands && !more_seen)
                 break;
             if (more_surv)
-                A.cand_cap_override = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, segmented ? 0 : 4 * H->cand_cap));
+                A.cand_cap_override = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, 4 * H->cand_cap));
             if (more_bands)
                 A.band_scale = std::max<uint64_t>(1, A.band_scale) * std::max<uint64_t>(2, (c[3] + H->band_cap - 1) / H->band_cap + 1);
             if (more_seen)
@@ -1620,8 +1631,8 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             // the count so far in stats.n_hits), not a reason to scan again
             H->n = c[0];
             H->counted = true;
-        } else if (c[2] != 0 || (segmented && c[1] > H->cand_cap)) {
-            // lists still too small, or a segmented scan overflowed: the whole range again, brute force
+        } else if (c[2] != 0) {
+            // lists still too small: the whole range again, brute force
             H->stats.fell_back = 1;
             use_filter = false;
             SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -1659,13 +1670,42 @@ static int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_
             uint64_t tile = std::max<uint64_t>(std::max<uint64_t>(1024, (warm * 8 + 255) & ~255ull), (total / want_tiles + 255) & ~255ull);
             tile = std::min<uint64_t>(tile, 1u << 20);
             std::vector<uint64_t> tab;
-            for (const auto &r : mg)
-                for (uint64_t lo = r.first; lo < r.second; lo += tile) {
-                    const uint64_t hi = std::min(lo + tile, r.second);
-                    tab.push_back(lo >= A.ctx_begin + warm ? lo - warm : A.ctx_begin);
-                    tab.push_back(lo);
-                    tab.push_back(hi);
+            const uint64_t *segs = nullptr;
+            if (segmented) { // every segment is a haystack of its own: the tiles follow the segment table
+                if (A.seg_offsets) {
+                    segs = A.seg_offsets;
+                } else {
+                    A.seg_host.resize(A.n_segments + 1);
+                    SPM_HIP_CHECK(ctx, hipMemcpyAsync(A.seg_host.data(), A.d_seg_offsets, (A.n_segments + 1) * sizeof(uint64_t),
+                                                      hipMemcpyDeviceToHost, ctx->stream));
+                    SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    segs = A.seg_host.data();
                 }
+            }
+            for (const auto &r : mg) {
+                if (!segs) {
+                    for (uint64_t lo = r.first; lo < r.second; lo += tile) {
+                        const uint64_t hi = std::min(lo + tile, r.second);
+                        tab.push_back(lo >= A.ctx_begin + warm ? lo - warm : A.ctx_begin);
+                        tab.push_back(lo);
+                        tab.push_back(hi);
+                    }
+                    continue;
+                }
+                // the segments that meet [r.first, r.second): the one holding r.first, then on
+                uint64_t sidx = (uint64_t)(std::upper_bound(segs, segs + A.n_segments + 1, r.first) - segs);
+                sidx = sidx ? sidx - 1 : 0;
+                for (; sidx < A.n_segments && segs[sidx] < r.second; ++sidx) {
+                    const uint64_t sb = segs[sidx], se = segs[sidx + 1];
+                    const uint64_t o_lo = std::max(r.first, sb), o_hi = std::min(r.second, se);
+                    for (uint64_t lo = o_lo; lo < o_hi; lo += tile) {
+                        const uint64_t hi = std::min(lo + tile, o_hi);
+                        tab.push_back(lo >= sb + warm ? lo - warm : sb); // (cold start inside the segment)
+                        tab.push_back(lo);
+                        tab.push_back(hi);
+                    }
+                }
+            }
             H->stats.fallback_spans = (uint32_t)std::min<uint64_t>(n_ovf, 0xFFFFFFFFu);
             if (!tab.empty()) {
                 if (tab.size() / 3 > 0xFFFFFFFFull) {

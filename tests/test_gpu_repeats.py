@@ -173,3 +173,57 @@ def test_exact_sets_with_and_without_repeat_needles(spm, ctx, oracle, algo):
         h1 = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=True, pos_offset=77).view()
         h2 = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=True, pos_offset=77).view()
         assert np.array_equal(h1, h2)
+
+
+@pytest.mark.parametrize("budget", [2, 24])
+def test_segmented_scan_falls_back_span_by_span(spm, ctx, oracle, budget):
+    """Independent haystacks stored back to back (spm_hip_scan_segments; the journaled-sequence search is one such scan):
+    spans whose survivors exceed a tiny budget give up and are scanned again by the brute-force kernel, with tiles that follow
+    the segment table -- not the whole scan.  Hits == per-segment brute-force scans == oracle; nothing spans two haystacks."""
+    rng = np.random.default_rng(31 + budget)
+    lens = [0, 7, 5000, 150, 149, 70000, 1, 33, 260000, 0, 2500, 1 << 20, 99, 400000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(offs[-1])
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    L, k = 100, 3
+    needles = []
+    for i in range(96):
+        s = int(rng.integers(0, len(lens)))
+        while lens[s] < 2 * L:
+            s = int(rng.integers(0, len(lens)))
+        at = int(offs[s]) + int(rng.integers(0, lens[s] - L))
+        nd = T[at:at + L].copy()
+        for e in range(i % (k + 1)):
+            nd[int(rng.integers(0, L))] = rng.integers(0, 4)
+        needles.append(nd)
+    for j, s in enumerate((2, 5, 8)):       # occurrences across a border between two haystacks: must NOT be reported
+        b = int(offs[s + 1])
+        T[b - 50:b + 50] = needles[j]
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    assert ps.filterable
+    ref = []
+    for s in range(len(lens)):
+        b, e = int(offs[s]), int(offs[s + 1])
+        if e > b:
+            ref.append(spm.scan(ctx, text, ps, b, e, engine=spm.ENGINE_BRUTE).view())
+    ref = np.concatenate(ref)
+    ref = ref[np.lexsort((ref["pos"], ref["pattern"]))]
+    os.environ["SPM_HIP_FILTER_SPAN_BUDGET"] = str(budget)
+    try:
+        h = spm.scan_segments(ctx, text, ps, offs, engine=spm.ENGINE_FILTER)
+        st = h.stats()
+        got = h.view()
+    finally:
+        del os.environ["SPM_HIP_FILTER_SPAN_BUDGET"]
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0 and st.fallback_spans > 0
+    assert len(ref) >= 90 and np.array_equal(got, ref)
+    for p in (0, 5, 50):
+        want = []
+        for s in range(len(lens)):
+            b, e = int(offs[s]), int(offs[s + 1])
+            if e - b >= 1:
+                r = oracle.myers(T[b:e], needles[p], k)
+                want += [(int(x) + b, int(sc)) for x, sc in zip(r["pos"], r["score"])]
+        mine = got[got["pattern"] == p]
+        assert sorted((int(a), int(c)) for a, c in zip(mine["pos"], mine["score"])) == sorted(want)
