@@ -199,7 +199,8 @@ int spm_hip_hits_device(spm_hits *hits, const void **device_records, uint64_t *n
 /* Copy the first min(n, cap) records into a caller-owned device buffer (e.g. a torch tensor that an RCCL
  * send/recv will read), asynchronously on the context's stream.  *n receives the number of hits. */
 int spm_hip_hits_copy_device(spm_hits *hits, void *device_dst, uint64_t cap, uint64_t *n);
-/* The same with a 16-byte header {n as uint64, 0} in front of the records: device_dst holds cap + 1 records' worth of bytes.
+/* The same with a 16-byte header {n as uint64, 0} in front of the records: device_dst (16-byte aligned) holds cap + 1
+ * records' worth of bytes; one kernel writes header and records.
  * This is the fixed-size [count | records] buffer one ncclAllGather per scan exchanges (libspm_amd.dist.gather_hits_fused):
  * the count is written from the host value the library already has, no second call from the caller. */
 int spm_hip_hits_copy_fused(spm_hits *hits, void *device_dst, uint64_t cap, uint64_t *n);

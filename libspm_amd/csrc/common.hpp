@@ -32,6 +32,7 @@ struct hits_block // device buffers + events of one scan result, recycled throug
     unsigned long long *d_count = nullptr;
     uint64_t cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool zeroed = false; // the counters were cleared when the block went back to the pool
 };
 
 struct spm_ctx
@@ -51,9 +52,7 @@ struct spm_ctx
     uint64_t band_slots = 0;
     bool band_dirty = false;
     unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs
-                                              // an extra staging hop on every scan); [13], [14]: header of hits_copy_fused
-    hipEvent_t fused_hdr_ev = nullptr;        // recorded behind the last header copy out of h_counters[13..14]
-    bool fused_hdr_pending = false;
+                                              // an extra staging hop on every scan)
 };
 
 struct spm_text
@@ -86,6 +85,13 @@ struct spm_hits
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     void *d_aux[2] = {nullptr, nullptr}; // segmented scans: tile table, segment offsets (freed with the hits)
+};
+
+struct pass_entry // key directory of one pass of the seed filter, in L2 (filter.hpp: resolve_kernel)
+{
+    const uint4 *ht; // {key, first entry, entries, -}, open addressing; an empty slot has .z == 0
+    uint32_t ht_mask;
+    uint32_t pad;
 };
 
 // scope guard for temporary device buffers: freed on every return path

@@ -35,7 +35,8 @@
 #include "brute.hpp"
 #include "common.hpp"
 #include "filter_shared.hpp"
-#include "synth.hpp"
+#include "pack.hpp"
+#include "hd.hpp" // mix64
 
 namespace spm_hip
 {
@@ -51,13 +52,6 @@ struct survivor
     uint32_t pad;        // pass (needle sub-batch) whose level-1 table it passed
 };
 constexpr uint32_t kSurvInvalid = 0xFFFFFFFFu;
-
-struct pass_entry // key directory of one pass, in L2
-{
-    const uint4 *ht; // {key, first entry, entries, -}, open addressing; an empty slot has .z == 0
-    uint32_t ht_mask;
-    uint32_t pad;
-};
 
 // What verification works on: a band of diagonals of one needle in one haystack (segment) that collected enough seed hits.
 // Bands are Bw diagonals wide, counted from `max_m` diagonals before the haystack's first symbol (so they are never
@@ -125,96 +119,6 @@ struct filter_params
     uint64_t *ovf_spans;      // [ovf_cap][2]: {first text index, symbols} of every span that gave up
     uint64_t ovf_cap;
 };
-
-// text bytes 16*lane .. 16*lane+15 of a chunk -> 32-bit word, base i at bits 2i..2i+1
-__device__ __forceinline__ uint32_t pack16(const uint4 v)
-{
-    const uint32_t W = 0x40100401u; // byte weights 1,4,16,64
-    const uint32_t p0 = __builtin_amdgcn_udot4(v.x, W, 0u, false);
-    const uint32_t p1 = __builtin_amdgcn_udot4(v.y, W, 0u, false);
-    const uint32_t p2 = __builtin_amdgcn_udot4(v.z, W, 0u, false);
-    const uint32_t p3 = __builtin_amdgcn_udot4(v.w, W, 0u, false);
-    return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
-}
-
-// dna5 haystacks (seqan3 ranks A0 C1 G2 N3 T4): same 2-bit word with T folded onto 3, plus a 16-bit mask of the N
-// positions; a window that contains an N cannot equal any (N-free) key and is dropped.  ~7 VALU per dword.
-__device__ __forceinline__ uint32_t pack16_dna5(const uint4 v, uint32_t &nmask)
-{
-    const uint32_t W = 0x40100401u, WN = 0x08040201u;
-    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-    uint32_t code = 0;
-    nmask = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t isT = (x[i] >> 2) & 0x01010101u;            // byte == 4
-        const uint32_t isN = x[i] & (x[i] >> 1) & 0x01010101u;     // byte == 3
-        code |= __builtin_amdgcn_udot4(x[i] - isT, W, 0u, false) << (8 * i);
-        nmask |= __builtin_amdgcn_udot4(isN, WN, 0u, false) << (4 * i);
-    }
-    return code;
-}
-
-// dna15 haystacks (seqan3 ranks A0 B1 C2 D3 G4 H5 K6 M7 N8 R9 S10 T11 V12 W13 Y14): A, C, G, T -> 0..3, every
-// ambiguity code marked like dna5's N (a window that holds one equals no key).  SWAR on the four bytes of a dword:
-// a key symbol is T (11) or an even rank <= 4; its code is rank >> 1 (T: 3).  ~14 VALU per dword.
-__device__ __forceinline__ uint32_t pack16_dna15(const uint4 v, uint32_t &nmask)
-{
-    const uint32_t W = 0x40100401u, WN = 0x08040201u;
-    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-    uint32_t code = 0;
-    nmask = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t t = x[i] ^ 0x0B0B0B0Bu;                                          // byte == 11 <=> zero byte
-        const uint32_t isT = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu) >> 7; // exact per-byte zero test
-        const uint32_t odd = x[i] & 0x01010101u;
-        const uint32_t big = ((x[i] + 0x7B7B7B7Bu) & 0x80808080u) >> 7;                   // byte >= 5
-        const uint32_t amb = (odd | big) & ~isT;
-        const uint32_t c2 = (((x[i] >> 1) & 0x03030303u) & ~(isT * 3u)) | (isT * 3u);
-        code |= __builtin_amdgcn_udot4(c2 & ~(amb * 3u), W, 0u, false) << (8 * i);
-        nmask |= __builtin_amdgcn_udot4(amb, WN, 0u, false) << (4 * i);
-    }
-    return code;
-}
-
-template <int SIG>
-__device__ __forceinline__ uint32_t pack16_sig(const uint4 v, uint32_t &nmask)
-{
-    if constexpr (SIG == 5)
-        return pack16_dna5(v, nmask);
-    else if constexpr (SIG == 15)
-        return pack16_dna15(v, nmask);
-    else {
-        nmask = 0;
-        return pack16(v);
-    }
-}
-
-__device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint64_t idx, uint64_t limit)
-{
-    // idx % 16 == 0.  Bytes at or beyond `limit` read as 0.
-    if (idx + 16 <= limit)
-        return *reinterpret_cast<const uint4 *>(text + idx);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int b = 0; b < 16; ++b)
-        if (idx + b < limit)
-            w[b >> 2] |= (uint32_t)text[idx + b] << (8 * (b & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-template <bool NT>
-__device__ __forceinline__ uint4 load16_stream(const uint8_t *p)
-{
-    if (NT) {
-        // streamed once: nontemporal keeps it from displacing the key table in L2 and measures +13 % on a pure
-        // 16 GiB read (tools/hbm_read_probe: 7.0 vs 6.2 TB/s)
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-        return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
-                          __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
-    }
-    return *reinterpret_cast<const uint4 *>(p);
-}
 
 // one atomic per wave: add the lanes' counts to a statistics counter (call with the wave converged)
 __device__ __forceinline__ void wave_count_add(unsigned long long *counter, uint32_t v)
@@ -926,48 +830,6 @@ __global__ __launch_bounds__(1024) void seed_filter_dense_kernel(const filter_pa
     surv_close(P, cand_chunk_of(P, lds), lane);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Optional 2-bit shadow of a dna4 haystack (spm_hip_text_pack): 16 symbols per uint32, same bit order as pack16.
-// A text that is scanned many times (one reference, many needle batches) is then streamed at a quarter of the
-// HBM traffic; hits are identical.  text_pack_kernel builds it in one pass and flags symbols outside {0..3}.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void text_pack_kernel(const uint8_t *__restrict__ text, uint64_t n,
-                                                        uint32_t *__restrict__ packed, uint64_t n_words,
-                                                        unsigned int *bad)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned int any_bad = 0;
-    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += stride) {
-        const uint4 v = load_text16(text, wi * 16, n);
-        any_bad |= (v.x | v.y | v.z | v.w) & 0xFCFCFCFCu;
-        packed[wi] = pack16(v);
-    }
-    if (any_bad)
-        atomicOr(bad, 1u);
-}
-
-// A borrowed haystack (spm_hip_text_wrap) is read once to make sure every symbol is a rank < sigma: the filter's 2-bit
-// packing would fold a stray byte into its neighbours' codes and could then miss an occurrence the brute-force engine
-// reports.
-__global__ __launch_bounds__(256) void text_validate_kernel(const uint8_t *__restrict__ text, uint64_t n, uint32_t sigma,
-                                                            unsigned int *bad)
-{
-    const uint64_t n_q = (n + 15) / 16;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned int any_bad = 0;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += stride) {
-        const uint4 v = load_text16(text, q * 16, n); // bytes past n read as 0
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                any_bad |= ((w[i] >> (8 * b)) & 0xFFu) >= sigma ? 1u : 0u;
-    }
-    if (any_bad)
-        atomicOr(bad, 1u);
-}
-
 // Same filter, fed from the shadow: one 16-byte load per lane = 4 words = 64 symbols; a wave-load ("p-chunk") covers
 // 4096 symbols.  U2 p-chunks per group, the next group's loads in flight.  The shadow is zero-padded to whole
 // p-chunks, so every load is unconditional; windows reaching past the text are dropped by the range check.
@@ -1596,7 +1458,10 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
                 own_b = R.seg_owned ? sb + (int64_t)R.seg_owned[seg] : sb;
                 own_e = se;
             }
-            fresh = e >= own_b + 1 && e <= own_e && seen_insert_raw(R.seen, R.seen_mask, R.overflow, pat, e);
+            // (R.seen == nullptr: every occurrence has exactly one sampled window and one entry, so nothing is reported
+            // twice -- unless spans give up and the brute-force kernel re-scans them: then the host runs the scan again
+            // with the dedupe set)
+            fresh = e >= own_b + 1 && e <= own_e && (!R.seen || seen_insert_raw(R.seen, R.seen_mask, R.overflow, pat, e));
         }
         const unsigned long long idx = wave_reserve_hits(R.hit_counter, fresh ? 1u : 0u);
         if (fresh && idx < R.hit_cap) {
