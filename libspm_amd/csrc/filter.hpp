@@ -955,6 +955,8 @@ struct verify_params
     uint32_t preselected;               // 1: the list holds only bands with enough seed hits, their table slots reset
     uint64_t band_cap;
     ulonglong2 *band_tab;               // band table (slots are given back as the bands are consumed), see band_value()
+    uint32_t table_mask, band_bits;     // ... its size - 1 and key layout (band_runs_kernel looks neighbours up)
+    uint32_t runs;                      // 1: band_runs_kernel has compacted the heads of runs; the list holds heads only
     const uint8_t *surplus; // per needle: seed hits a band needs (seeds - k); nullptr = 1 for every needle
     uint32_t Bw;            // diagonals per band
     uint32_t overlap;       // 1: bands extend k + 1 diagonals into the next one (sets with surplus seeds)
@@ -1731,6 +1733,137 @@ __global__ __launch_bounds__(256) void band_select_kernel(const verify_params P,
     }
 }
 
+// ---- runs of adjacent bands ------------------------------------------------------------------------------------------
+// A repeat stretch of the text that a needle (nearly) matches is hit on a hundred diagonals in a row: three, four bands of
+// 32, each of which would be verified on its own -- |P| + k columns of cold start each time for 32 + 2k end positions --
+// and every one of its hits would go through the dedupe set (a compare-and-swap in a table of a gigabyte: memory-side
+// atomics are what the verification of a repeat-rich text runs out of first).  band_runs_kernel (sets without surplus
+// seeds, long band lists only) looks every band's neighbours up in the band table BEFORE the verification gives the slots
+// back: a band whose predecessor exists is a FOLLOWER (not verified on its own), a band without one -- or at a multiple of
+// kRunMax, so that no lane gets more than kRunMax bands (a wave waits for its longest lane: four bands are 237 columns
+// against the 141 of one, and already save 58 % of four cold starts) -- is the HEAD of a run and records how many bands
+// follow it and the last hit diagonal of the last one.  The heads are compacted into a list of their own; the verification
+// runs through the diagonals of a whole run with one cold start.  In band_rec::val (low 11 bits, 0 when the kernel did not run):
+constexpr uint32_t kRunAnalysed = 0x400u; // band_runs_kernel has looked at this band
+constexpr uint32_t kRunFollower = 0x200u; // ... and found its predecessor: the head of the run covers it
+constexpr uint32_t kRunLenShift = 5, kRunLenMask = 0x3u, kRunHiMask = 0x1Fu; // head: followers (0..3), last hit diagonal (0..31)
+// head: the band right before / right behind the run exists too (the run was cut at a multiple of kRunMax): only there can
+// another verification report the same (needle, end) -- the seeds of one occurrence lie within k diagonals of each other,
+// i.e. in one band or in two adjacent ones, and adjacent bands belong to one run unless the cut falls between them.  So a
+// head asks the dedupe set only about the end positions within reach of such a side, and reports the rest as they come.
+constexpr uint32_t kRunTouchLeft = 0x80u, kRunTouchRight = 0x100u;
+constexpr uint32_t kRunMax = 4;
+constexpr uint32_t kHitStage = 192; // hit records a wave of verify_kernel collects before it moves them out
+
+__device__ __forceinline__ uint32_t band_lookup(const verify_params &P, unsigned long long bkey)
+{
+    uint32_t s2 = (uint32_t)mix64(bkey) & P.table_mask;
+    for (uint32_t tries = 0; tries < 8192; ++tries) {
+        const unsigned long long o = P.band_tab[s2].x;
+        if (o == bkey)
+            return s2;
+        if (o == kBandEmpty)
+            return 0xFFFFFFFFu;
+        s2 = (s2 + 1) & P.table_mask;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// One pass over the band list: classify every band (head / follower), write the code into its record, and compact the heads
+// into `heads` (a workgroup takes 2048 records at a time and reserves room for its heads with ONE atomic -- a wave-level
+// reservation would be 500 000 atomics on one word for a 30 M list).  The verification then runs over `heads` only and
+// leaves the table alone; band_release_kernel gives every slot of the original list back afterwards.
+__global__ __launch_bounds__(256) void band_runs_kernel(const verify_params P, band_rec *bands, band_rec *heads,
+                                                        unsigned long long *head_count)
+{
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long chunk_base;
+    unsigned long long n = P.counters[P.band_counter];
+    if (n > P.band_cap)
+        n = P.band_cap;
+    constexpr uint32_t PER = 8;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * (256 * PER); c0 < n; c0 += (uint64_t)gridDim.x * (256 * PER)) {
+        band_rec mine[PER];
+        uint32_t head_mask = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint64_t i = c0 + (uint64_t)j * 256 + tid;
+            mine[j].val = kBandInvalid;
+            if (i >= n)
+                continue;
+            band_rec c = bands[i];
+            if (c.val == kBandInvalid)
+                continue;
+            const unsigned long long base = ((unsigned long long)(c.val >> 11) << 43) | ((unsigned long long)c.seg << P.band_bits);
+            uint32_t code = kRunAnalysed;
+            const bool pred = c.band > 0 && band_lookup(P, base | (unsigned long long)(c.band - 1)) != 0xFFFFFFFFu;
+            if (c.band % kRunMax != 0 && pred) {
+                code |= kRunFollower;
+            } else {
+                uint32_t followers = 0, last = c.slot;
+                bool cut = true; // the run ends at a multiple of kRunMax (then the band behind it may exist)
+                for (uint32_t r = 1; r < kRunMax && (c.band + r) % kRunMax != 0; ++r) {
+                    const uint32_t s2 = band_lookup(P, base | (unsigned long long)(c.band + r));
+                    if (s2 == 0xFFFFFFFFu) {
+                        cut = false;
+                        break;
+                    }
+                    followers = r;
+                    last = s2;
+                }
+                const bool succ = cut && band_lookup(P, base | (unsigned long long)(c.band + followers + 1)) != 0xFFFFFFFFu;
+                const unsigned long long v = band_value(P.band_tab[last].y, false);
+                const uint32_t hi = v ? (uint32_t)(63 - __clzll((long long)v)) : 0u;
+                code |= (followers << kRunLenShift) | (hi & kRunHiMask) | (pred ? kRunTouchLeft : 0u) | (succ ? kRunTouchRight : 0u);
+                head_mask |= 1u << j;
+                ++cnt;
+            }
+            c.val = (c.val & ~0x7FFu) | code;
+            mine[j] = c;
+        }
+        // where this thread's heads go: exclusive prefix over the workgroup, one reservation per chunk
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= (uint32_t)o)
+                incl += up;
+        }
+        if (lane == 63)
+            wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            wave_off += w < wave ? wave_tot[w] : 0u;
+            total += wave_tot[w];
+        }
+        if (tid == 0)
+            chunk_base = total ? atomicAdd(head_count, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        uint64_t pos = chunk_base + wave_off + incl - cnt;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j)
+            if (head_mask & (1u << j))
+                heads[pos++] = mine[j]; // (<= the entries of the input list)
+        __syncthreads();
+    }
+}
+
+// ... and after the verification of the heads: every band of the original list gives its table slot back
+__global__ __launch_bounds__(256) void band_release_kernel(const verify_params P, const band_rec *bands, uint32_t counter)
+{
+    unsigned long long n = P.counters[counter];
+    if (n > P.band_cap)
+        n = P.band_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const band_rec c = bands[i];
+        if (c.val != kBandInvalid)
+            band_release(P.band_tab, c.slot);
+    }
+}
+
 // What a band record stands for (verification side).  Returns false if the band has too few seed hits, lies outside the
 // owned range, or is an unused list slot.  Consumes the band's table slot (the table is empty again after the scan).
 struct band_geom
@@ -1739,6 +1872,8 @@ struct band_geom
     int64_t m, k;
     int64_t e_lo, e_hi; // exclusive end positions it answers for
     int64_t ws;         // cold start
+    int64_t dd_lo, dd_hi; // end positions <= dd_lo or >= dd_hi go through the dedupe set (heads of runs: the rest cannot
+                          // be reported by anybody else); everything, unless band_runs_kernel has analysed the band
 };
 
 __device__ __forceinline__ bool decode_band(const verify_params &P, const band_rec &c, bool consume, band_geom &g)
@@ -1751,6 +1886,8 @@ __device__ __forceinline__ bool decode_band(const verify_params &P, const band_r
         v = band_value(P.band_tab[c.slot].y, P.overlap != 0);
         if (consume)
             band_release(P.band_tab, c.slot);
+        if (c.val & kRunFollower)
+            return false; // the head of its run verifies this band's diagonals too
         if (P.overlap ? (uint32_t)v < (P.surplus ? (uint32_t)P.surplus[g.pat] : 1u) : v == 0)
             return false;
     }
@@ -1765,15 +1902,28 @@ __device__ __forceinline__ bool decode_band(const verify_params &P, const band_r
     }
     // diagonals d .. d + span: needle position 0 <-> text index d.  Bands that do not overlap know which of their
     // diagonals were hit: an isolated seed hit is verified over its own diagonal, a repeat stretch over the whole band
-    int64_t d = hay_b - (int64_t)P.max_m + (int64_t)c.band * (int64_t)P.Bw;
+    const int64_t band_base = hay_b - (int64_t)P.max_m + (int64_t)c.band * (int64_t)P.Bw;
+    int64_t d = band_base;
     int64_t span = (int64_t)P.Bw - 1 + (P.overlap ? g.k + 1 : 0);
     if (!P.overlap) {
-        const int lo = __ffsll((long long)v) - 1, hi = 63 - __clzll((long long)v);
+        const int lo = __ffsll((long long)v) - 1;
+        int hi = 63 - __clzll((long long)v);
+        if (c.val & kRunAnalysed) // the head of a run of adjacent bands: through the last hit diagonal of its last band
+            hi = (int)(((c.val >> kRunLenShift) & kRunLenMask) * P.Bw + (c.val & kRunHiMask));
         d += lo;
         span = hi - lo;
     }
     g.e_lo = d + g.m - g.k;
     g.e_hi = d + g.m + g.k + span;
+    g.dd_lo = INT64_MAX; // (every end position is <= this: all of them go through the dedupe set)
+    g.dd_hi = INT64_MIN;
+    if (!P.overlap && (c.val & kRunAnalysed) && !P.seg_offsets) {
+        const int64_t next_base = band_base + (int64_t)(((c.val >> kRunLenShift) & kRunLenMask) + 1) * (int64_t)P.Bw;
+        // the run before ends on a diagonal < band_base: its end positions reach band_base - 1 + m + k; the run behind
+        // starts on a diagonal >= next_base: its end positions begin at next_base + m - k
+        g.dd_lo = (c.val & kRunTouchLeft) ? band_base + g.m + g.k : INT64_MIN;
+        g.dd_hi = (c.val & kRunTouchRight) ? next_base + g.m - g.k - 1 : INT64_MAX;
+    }
     // ownership: last symbol e-1 in [own_b, own_e)
     if (g.e_lo < own_b + 1)
         g.e_lo = own_b + 1;
@@ -1796,14 +1946,34 @@ __device__ __forceinline__ bool decode_band(const verify_params &P, const band_r
 template <int NWN>
 __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 {
-    extern __shared__ uint32_t vlds[]; // [sigma + 1][NWN][blockDim.x] words, then [2*max_k + 1 + max_span][blockDim.x] uint16
+    // [sigma + 1][NWN][blockDim.x] words, then [16][blockDim.x] uint16: the hits of one text block, then per wave kHitStage
+    // hit records on their way out
+    extern __shared__ uint32_t vlds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t nthr = blockDim.x;
     const uint32_t rows = P.sigma + 1;
     uint16_t *hitbuf = reinterpret_cast<uint16_t *>(vlds + (size_t)rows * NWN * nthr);
-    const uint32_t n_slots = 2 * P.max_k + 1 + P.max_span;
-    for (uint32_t r = 0; r < n_slots; ++r)
-        hitbuf[(size_t)r * nthr + tid] = 0;
+    // Hits leave through a per-wave staging area: a repeat-rich text reports tens of millions of them, and one atomic on
+    // the hit counter per wave and text block would be a million atomics on one word (~100 per microsecond).  The wave
+    // appends to its stage without atomics and moves kHitStage records out at a time: one atomic, coalesced stores.
+    spm_hit *stage = reinterpret_cast<spm_hit *>(hitbuf + (size_t)16 * nthr) + (size_t)(tid >> 6) * kHitStage;
+    uint32_t n_staged = 0; // (wave-uniform)
+    const uint32_t lane = tid & 63;
+    auto flush = [&]() {
+        if (n_staged == 0)
+            return;
+        unsigned long long base = 0;
+        if (lane == 0)
+            base = atomicAdd(P.hit_counter, (unsigned long long)n_staged);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+        for (uint32_t i = lane; i < n_staged; i += 64)
+            if (base + i < P.hit_cap)
+                P.hits[base + i] = stage[i];
+        n_staged = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     unsigned long long n_cand = P.counters[P.band_counter];
     if (n_cand > P.band_cap)
         n_cand = P.band_cap; // overflow is handled by the host
@@ -1821,7 +1991,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         g.e_hi = -1;
         g.ws = 0;
         // (false: an unused list slot, too few seed hits, or nothing owned)
-        const bool active = ci < n_cand && decode_band(P, P.bands[ci], true, g);
+        // (runs: the list holds heads only and band_release_kernel gives the slots back afterwards)
+        const bool active = ci < n_cand && decode_band(P, P.bands[ci], P.runs == 0, g);
         if (active)
             ++n_valid;
         const uint32_t pat = g.pat;
@@ -1833,7 +2004,6 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
 #pragma unroll
                 for (int w = 0; w < NWN; ++w)
                     vlds[((size_t)r * NWN + w) * nthr + tid] = src[((size_t)r * P.nw_table + w) * 64];
-        bool any_hit = false;
         myers_lane<NWN, false> L;
         {
             const int32_t off = NWN * 32 - (int32_t)m;
@@ -1849,66 +2019,95 @@ __global__ __launch_bounds__(256) void verify_kernel(const verify_params P)
         uint4 nxt = make_uint4(0, 0, 0, 0);
         if (active)
             nxt = load_text16(P.text, (uint64_t)blk0, P.text_alloc);
-        // columns in 32-bit terms relative to the cold start: rel = p - ws in [0, n_cols); end position slot = rel - rel_lo
+        // columns in 32-bit terms relative to the cold start: rel = p - ws in [0, n_cols); end positions from rel_lo on
         const uint32_t n_cols = (uint32_t)(e_hi - ws);
         const uint32_t rel_lo = (uint32_t)(e_lo - 1 - ws);
         const uint32_t sigma = P.sigma;
         uint32_t rel0 = (uint32_t)(blk0 - ws); // (wraps below zero for the symbols of the first block before ws)
-        for (int64_t blk = blk0; blk < e_hi; blk += 16, rel0 += 16) {
-            const uint4 cur = nxt;
-            if (blk + 16 < e_hi)
-                nxt = load_text16(P.text, (uint64_t)(blk + 16), P.text_alloc);
-            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+        // The text goes by in 16-symbol blocks; the wave steps through them together (trip count: its longest lane -- the
+        // head of a run of bands has up to 1.7 times the columns of a single band) and emits the hits of a block right
+        // behind it, all lanes at once: one CAS per hit that needs the dedupe set, then into the wave's stage.
+        const uint32_t my_blocks = active ? (uint32_t)((e_hi - blk0 + 15) >> 4) : 0u;
+        uint32_t max_blocks = my_blocks;
+        for (int o = 32; o > 0; o >>= 1)
+            max_blocks = max(max_blocks, (uint32_t)__shfl_xor((int)max_blocks, o));
+        max_blocks = (uint32_t)__builtin_amdgcn_readfirstlane(max_blocks);
+        for (uint32_t bi = 0; bi < max_blocks; ++bi, rel0 += 16) {
+            const int64_t blk = blk0 + 16 * (int64_t)bi;
+            uint32_t hitmask = 0;
+            if (bi < my_blocks) {
+                const uint4 cur = nxt;
+                if (bi + 1 < my_blocks)
+                    nxt = load_text16(P.text, (uint64_t)(blk + 16), P.text_alloc);
+                const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t rel = rel0 + (uint32_t)i;
-                if (rel >= n_cols)
-                    continue;
-                uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 0xFF;
-                sym = sym < sigma ? sym : sigma;
-                L.step_strided(vlds + ((size_t)sym * NWN) * nthr + tid, nthr);
-                if (L.score <= (int32_t)k && rel >= rel_lo) {
-                    // remember the hit; emission is deferred until the whole wave has finished scanning so that the
-                    // CAS / append atomics (1-2 us each) are issued once per end-position slot for all lanes together
-                    // instead of stalling the wave at ~every lane's own hit
-                    hitbuf[(size_t)(rel - rel_lo) * nthr + tid] = (uint16_t)(L.score + 1);
-                    any_hit = true;
-                }
-            }
-        }
-        // ---- deferred emission: slot r = end position e_lo + r ----
-        if (__ballot(any_hit) != 0) {
-            const int32_t nr = any_hit ? (int32_t)(e_hi - e_lo) + 1 : 0;
-            // pass 1: dedupe across the seeds / bands of one occurrence; what stays in the slots is new
-            uint32_t fresh = 0;
-            for (int32_t r = 0; r < nr; ++r) {
-                const uint32_t sc1 = hitbuf[(size_t)r * nthr + tid];
-                if (sc1) {
-                    if (seen_insert(P, pat, e_lo + r))
-                        ++fresh;
-                    else
-                        hitbuf[(size_t)r * nthr + tid] = 0;
-                }
-            }
-            // pass 2: one reservation for the wave, then every lane writes its run
-            unsigned long long idx = wave_reserve_hits(P.hit_counter, fresh);
-            for (int32_t r = 0; r < nr; ++r) {
-                const uint32_t sc1 = hitbuf[(size_t)r * nthr + tid];
-                hitbuf[(size_t)r * nthr + tid] = 0;
-                if (sc1) {
-                    if (idx < P.hit_cap) {
-                        const int64_t e = e_lo + r;
-                        spm_hit h;
-                        h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
-                        h.pattern = pat;
-                        h.score = (int32_t)sc1 - 1;
-                        P.hits[idx] = h;
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t rel = rel0 + (uint32_t)i;
+                    if (rel >= n_cols)
+                        continue;
+                    uint32_t sym = (words[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                    sym = sym < sigma ? sym : sigma;
+                    L.step_strided(vlds + ((size_t)sym * NWN) * nthr + tid, nthr);
+                    if (L.score <= (int32_t)k && rel >= rel_lo) {
+                        hitbuf[(size_t)i * nthr + tid] = (uint16_t)(L.score + 1);
+                        hitmask |= 1u << i;
                     }
-                    ++idx;
                 }
             }
+            if (__ballot(hitmask != 0) == 0)
+                continue;
+            // pass 1: dedupe across the seeds / bands of one occurrence; what stays in `keep` is new
+            uint32_t fresh = 0, keep = 0;
+            for (uint32_t mm = hitmask; mm != 0; mm &= mm - 1) {
+                const uint32_t i = (uint32_t)__ffs(mm) - 1u;
+                const int64_t e = blk + (int64_t)i + 1; // (exclusive end of an occurrence ending at symbol blk + i)
+                if ((e > g.dd_lo && e < g.dd_hi) || seen_insert(P, pat, e)) {
+                    ++fresh;
+                    keep |= 1u << i;
+                }
+            }
+            // pass 2: into the wave's stage (every lane behind the lanes before it)
+            uint32_t incl = fresh;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= (uint32_t)o)
+                    incl += up;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, 63));
+            if (total == 0)
+                continue;
+            if (n_staged + total > kHitStage)
+                flush();
+            unsigned long long direct = 0; // more hits in one block than the stage holds: straight to the hit list
+            const bool staged = total <= kHitStage;
+            if (!staged) {
+                if (lane == 0)
+                    direct = atomicAdd(P.hit_counter, (unsigned long long)total);
+                direct = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(direct >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)direct);
+            }
+            uint32_t at = n_staged + incl - fresh;
+            for (uint32_t mm = keep; mm != 0; mm &= mm - 1) {
+                const uint32_t i = (uint32_t)__ffs(mm) - 1u;
+                const int64_t e = blk + (int64_t)i + 1;
+                spm_hit h;
+                h.pos = (P.report_begin ? (uint64_t)(e - m) : (uint64_t)e) + P.pos_offset;
+                h.pattern = pat;
+                h.score = (int32_t)hitbuf[(size_t)i * nthr + tid] - 1;
+                if (staged)
+                    stage[at] = h;
+                else if (direct + at < P.hit_cap)
+                    P.hits[direct + at] = h;
+                ++at;
+            }
+            if (staged)
+                n_staged += total;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    flush();
     wave_count_add(P.hit_counter + 7, n_valid); // bands verified
 }
 

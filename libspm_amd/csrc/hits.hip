@@ -173,3 +173,9 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
     delete h;
 }
 
+
+void spm_warm_hits_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)hits_fused_copy_kernel);
+}

@@ -116,3 +116,11 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
               const spm_scan_opts *opts_in, const void *state_in, void *state_out, const uint64_t *seg_offsets,
               uint64_t n_segments, spm_hits **out, const uint64_t *d_seg_offsets = nullptr,
               const uint32_t *d_seg_owned = nullptr, const std::function<int(spm_hits *)> *after_launch = nullptr);
+
+// Every translation unit with kernels is a code object of its own, loaded by the HIP runtime at the first launch out of
+// it (~1-3 ms each).  spm_hip_init loads them all, so that the first scan of a process does not pay for it.
+void spm_warm_text_kernels();
+void spm_warm_brute_kernels();
+void spm_warm_filter_kernels();
+void spm_warm_hits_kernels();
+void spm_warm_jst_kernels();

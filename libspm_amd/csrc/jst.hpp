@@ -1250,3 +1250,9 @@ extern "C" int spm_hip_jst_synth_variants(uint64_t seed_text, uint64_t seed_var,
     *alt_pool_len = np;
     return SPM_OK;
 }
+
+void spm_warm_jst_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)spm_hip::jst_fanout_kernel);
+}

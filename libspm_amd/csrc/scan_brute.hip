@@ -174,3 +174,9 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
     return SPM_OK;
 }
 
+
+void spm_warm_brute_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)myers_cutoff_kernel<4>);
+}

@@ -10,10 +10,10 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
     // LDS holds (sigma+1)*NWN words per thread; keep the block within ~128 KiB
     uint32_t threads = 256;
-    const size_t per_thread = (size_t)(V.sigma + 1) * NWN * 4 + 2 * (2 * (size_t)V.max_k + 1 + V.max_span);
+    const size_t per_thread = (size_t)(V.sigma + 1) * NWN * 4 + 2 * 16; // match masks + the hits of one 16-symbol block
     while (threads > 64 && per_thread * threads > 128 * 1024)
         threads >>= 1;
-    const size_t lds = per_thread * threads;
+    const size_t lds = per_thread * threads + (size_t)(threads / 64) * kHitStage * sizeof(spm_hit);
     hipFuncSetAttribute((const void *)verify_kernel<NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_kernel<NWN>), grid, dim3(threads), lds, s, V);
 }
@@ -171,7 +171,7 @@ int run_filter(const scan_args &A)
         seen_slots <<= 1;
     const size_t surv_bytes = surv_cap * sizeof(survivor);
     const size_t seen_bytes = seen_slots * sizeof(unsigned long long);
-    const size_t band_bytes = band_cap * sizeof(band_rec) * (overlap ? 2 : 1); // (+ the selected bands of overlapping sets)
+    const size_t band_bytes = band_cap * sizeof(band_rec) * 2; // (+ the selected bands of overlapping sets / the heads of runs)
     const size_t ovf_bytes = kOvfCap * 2 * sizeof(uint64_t);
     int rc = ensure_scratch(ctx, surv_bytes + seen_bytes + band_bytes + ovf_bytes);
     if (rc != SPM_OK)
@@ -553,6 +553,23 @@ int run_filter(const scan_args &A)
     V.n_segments = n_seg;
     V.seg_owned = A.d_seg_owned;
     V.band_counter = 3;
+    V.table_mask = (uint32_t)(band_slots - 1);
+    V.band_bits = 43 - seg_bits;
+    // runs of adjacent bands (filter.hpp, band_runs_kernel): when earlier scans of this set left a long band list -- a
+    // repeat-rich text --, sets without surplus seeds, lane-per-band verification
+    const bool runs = !overlap && !exact_hits && !use_wave && Bw <= 32 && !A.need_seen && env_int("SPM_HIP_VERIFY_RUNS", 1) != 0 &&
+                      ps->band_hint >= (uint64_t)std::max(0, env_int("SPM_HIP_VERIFY_RUNS_MIN_BANDS", 65536));
+    if (runs) {
+        // (heads report most end positions without asking the dedupe set: if a span gives up, the brute-force re-scan
+        // could report them again -- the scan then runs once more without runs, as for exact sets without the set)
+        const_cast<scan_args &>(A).seen_skipped = true;
+        hipLaunchKernelGGL(band_runs_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, V, d_bands, d_bands + band_cap,
+                           H->d_count + 11);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+        V.runs = 1;
+        V.bands = d_bands + band_cap;
+        V.band_counter = 11;
+    }
     if (overlap) {
         hipLaunchKernelGGL(band_select_kernel, dim3(ctx->n_cu * 2), dim3(256), 0, ctx->stream, V, d_bands + band_cap,
                            H->d_count + 10);
@@ -574,9 +591,19 @@ int run_filter(const scan_args &A)
         launch_verify(nwn, V, dim3(vgrid), ctx->stream);
     }
     SPM_HIP_CHECK(ctx, hipGetLastError());
+    if (runs) {
+        hipLaunchKernelGGL(band_release_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, V, d_bands, 3u);
+        SPM_HIP_CHECK(ctx, hipGetLastError());
+    }
     SPM_HIP_CHECK(ctx, hipEventRecord(H->ev[3], ctx->stream));
     H->cand_cap = surv_cap;
     H->band_cap = band_cap;
     return SPM_OK;
 }
 
+
+void spm_warm_filter_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)resolve_kernel);
+}

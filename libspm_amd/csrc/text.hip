@@ -39,6 +39,35 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
         ctx->own_stream = true;
     }
     SPM_HIP_CHECK(none, hipHostMalloc(&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+    // what the first scan would otherwise allocate in front of its kernels (~0.1 ms per hipMalloc / event): a first piece of
+    // scratch (survivor / band lists of a text up to ~2 GiB) and one recycled hit block of the default capacity
+    if (hipMalloc(&ctx->d_scratch, (size_t)64 << 20) == hipSuccess)
+        ctx->scratch_bytes = (size_t)64 << 20;
+    else
+        ctx->d_scratch = nullptr;
+    {
+        hits_block b;
+        b.cap = 1ull << 20;
+        bool ok = hipMalloc(&b.d_hits, b.cap * sizeof(spm_hit)) == hipSuccess &&
+                  hipMalloc(&b.d_count, 16 * sizeof(unsigned long long)) == hipSuccess;
+        for (int e = 0; e < 4 && ok; ++e)
+            ok = hipEventCreate(&b.ev[e]) == hipSuccess;
+        if (ok && hipMemsetAsync(b.d_count, 0, 16 * sizeof(unsigned long long), ctx->stream) == hipSuccess) {
+            b.zeroed = true;
+            ctx->pool.push_back(b);
+        } else {
+            hipFree(b.d_hits);
+            hipFree(b.d_count);
+            for (int e = 0; e < 4; ++e)
+                if (b.ev[e])
+                    hipEventDestroy(b.ev[e]);
+        }
+    }
+    spm_warm_text_kernels();
+    spm_warm_brute_kernels();
+    spm_warm_filter_kernels();
+    spm_warm_hits_kernels();
+    spm_warm_jst_kernels();
     *out = ctx.release();
     return SPM_OK;
 }
@@ -307,3 +336,9 @@ extern "C" void spm_hip_synth_repeat_text(uint64_t seed, uint32_t repeat_ppm, ui
 extern "C" uint64_t spm_hip_mix64(uint64_t z) { return mix64(z); }
 
 extern "C" const char *spm_hip_version(void) { return "libspm_hip 0.2 (gfx950)"; }
+
+void spm_warm_text_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)synth_text_kernel);
+}

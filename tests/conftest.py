@@ -21,6 +21,14 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def spm():
+    # torch ships a HIP runtime of its own; libspm_hip.so links the system one.  The two coexist when torch initialises
+    # first (as in bench.py), so a test process that uses both lets it: tests that allocate torch tensors on the GPU must not
+    # depend on another test having touched torch before them.
+    try:
+        import torch
+        torch.cuda.is_available() and torch.cuda.current_device()
+    except Exception:
+        pass
     import libspm_amd as S
     S.capi.lib()  # fails loudly if libspm_hip.so is missing
     return S

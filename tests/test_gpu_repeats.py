@@ -227,3 +227,41 @@ def test_segmented_scan_falls_back_span_by_span(spm, ctx, oracle, budget):
                 want += [(int(x) + b, int(sc)) for x, sc in zip(r["pos"], r["score"])]
         mine = got[got["pattern"] == p]
         assert sorted((int(a), int(c)) for a, c in zip(mine["pos"], mine["score"])) == sorted(want)
+
+
+@pytest.mark.parametrize("ppm,every", [(50000, 8), (120000, 4)])
+def test_band_runs_verify_adjacent_bands_once(spm, ctx, oracle, ppm, every):
+    """Runs of adjacent bands (a repeat stretch that a needle nearly matches is hit on a hundred diagonals in a row) are
+    verified by their head with ONE cold start (filter.hpp: band_runs_kernel).  Forced here for a short band list; a
+    5 %-shaped 64 MiB text (and a 12 % one): hits == the scan without runs == the CPU oracle, nothing reported twice."""
+    n = 1 << 26
+    text = ctx.generate_repeats(SEED_TEXT, 0, n, ppm)
+    needles = [spm.synth_repeat_pattern(SEED_TEXT, SEED_PAT, n, p, 100, 3, ppm, every)[0] for p in range(64)]
+    ps = ctx.patterns(spm.ALGO_MYERS, needles, k=3)
+    os.environ["SPM_HIP_VERIFY_RUNS"] = "0"
+    try:
+        plain = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+        st0 = plain.stats()
+        want = plain.view()
+    finally:
+        del os.environ["SPM_HIP_VERIFY_RUNS"]
+    os.environ["SPM_HIP_VERIFY_RUNS_MIN_BANDS"] = "0"
+    try:
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, max_hits=1 << 24)
+        st = h.stats()
+        got = h.view()
+    finally:
+        del os.environ["SPM_HIP_VERIFY_RUNS_MIN_BANDS"]
+    assert st.engine_used == spm.ENGINE_FILTER and st.fell_back == 0 and st0.fell_back == 0
+    assert len(want) > 100 and np.array_equal(got, want)
+    assert st.n_bands < st0.n_bands                      # followers are not verified on their own
+    assert len(set(_hits_list(got))) == len(got)
+    # the oracle, on the first 8 MiB (one sequential pass per needle) and for three needles on all of it
+    T8 = text.download(0, 1 << 23)
+    ref = oracle.scan_multi(oracle.MYERS, T8, needles, k=3, threads=8)
+    assert np.array_equal(got[got["pos"] <= (1 << 23)], ref)
+    T = text.download(0, n)
+    for p in (0, every, 63):
+        r = oracle.myers(T, needles[p], 3)
+        mine = got[got["pattern"] == p]
+        assert np.array_equal(mine["pos"], r["pos"]) and np.array_equal(mine["score"], r["score"])
