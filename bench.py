@@ -258,7 +258,7 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": c5_traffic(int(st.context_symbols), engine_used),
             "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_cutoff_kernel",
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": int(st.context_symbols),
@@ -292,6 +292,18 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
             result["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": 0, "kind": "port",
                                       "sample": f"unavailable: {e}"}
     return result
+
+
+def c5_traffic(context_symbols, engine_used):
+    """HBM bytes per launch of C5's streaming kernel from the PMC passes (profiles/pmc_traffic.json), if they were taken on
+    this exact context buffer."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("c5")
+        if pm and pm.get("algorithmic_bytes_per_launch") == context_symbols and engine_used == "filter":
+            return pm["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(algo, L, kmax, n_pat_full, n_total, budget_s=15.0):
@@ -662,7 +674,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_brute_kernel",
+            "kernel": ("seed_filter_dense_kernel" if bs.dense else "seed_filter_kernel") if engine_used == "filter" else "myers_brute_kernel",
             "kernel_ms": k_ms,
             "launches_per_step": launches / max(args.steps, 1),
             "algorithmic_bytes_per_launch": hi - lo,

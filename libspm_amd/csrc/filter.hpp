@@ -666,7 +666,9 @@ __device__ __forceinline__ void dense_drain(const filter_params &P, dense_queue 
     }
 }
 
-template <int UU, int NP>
+// S == 0: the anchored windows of a dense pass (NP patterns).  S = 1, 2: EVERY S-th window of a sparse pass whose level 1 is
+// the presence table (hash variant 4): the same number for every lane, at fixed places -- unrolled, no search for set bits.
+template <int UU, int NP, int S, bool KM>
 __device__ __forceinline__ void dense_group(const filter_params &P, const uint4 (&cur)[UU], uint64_t gbase, uint64_t span_base,
                                             uint32_t &carry_in, uint32_t lane, const uint32_t *lds, dense_queue &Q, uint32_t &qn)
 {
@@ -685,25 +687,41 @@ __device__ __forceinline__ void dense_group(const filter_params &P, const uint4 
     for (int j = 0; j < UU; j += 2) {
         constexpr bool pair = UU > 1;
         const uint32_t w0 = w[j], p0 = prev[j], w1 = w[pair ? j + 1 : j], p1 = prev[pair ? j + 1 : j];
-        // the anchored windows of two words in one mask: bit b = word j + (b & 1), window (b >> 1) + 1
-        uint32_t todo = dense_select<NP>(P, w0, p0);
-        if (pair)
-            todo |= dense_select<NP>(P, w1, p1) << 1;
-        // level 1, every lane for itself (a lane runs as long as it has anchored windows -- no wave-wide steps in here, the
-        // loop is what this kernel spends its time in): which of them have their presence bit set
+        const uint32_t kmask = KM ? P.key_mask : 0xFFFFFFFFu;
+        static_assert(kDenseBloomBits == 20, "the word address below takes bits 5..19 of the index");
+        // pm: bit b = word j + (b & 1), window (b >> 1) + 1 has its presence bit set
         uint32_t pm = 0;
-        if (P.dense_debug & 2u)
-            todo = 0;
-        while (todo != 0) {
-            const uint32_t b = (uint32_t)__ffs(todo) - 1u;
-            todo &= todo - 1;
-            const bool odd = (b & 1u) != 0;
-            const uint64_t both = ((uint64_t)(odd ? w1 : w0) << 32) | (odd ? p1 : p0);
-            const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u)); // window d = (b >> 1) + 1 starts 2 d bits in
-            const uint32_t h = key ^ (key >> 13); // dense_bloom_index(key) = h & (2^20 - 1): word h >> 5, bit h & 31
-            static_assert(kDenseBloomBits == 20, "the word address below takes bits 5..19 of the index");
-            const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + ((h >> 3) & 0x1FFFCu));
-            pm |= __builtin_amdgcn_ubfe(word, h, 1) << b;
+        if constexpr (S == 0) {
+            // the anchored windows of two words in one mask
+            uint32_t todo = dense_select<NP>(P, w0, p0);
+            if (pair)
+                todo |= dense_select<NP>(P, w1, p1) << 1;
+            // level 1, every lane for itself (a lane runs as long as it has anchored windows -- no wave-wide steps in
+            // here, the loop is what this kernel spends its time in): which of them have their presence bit set
+            if (P.dense_debug & 2u)
+                todo = 0;
+            while (todo != 0) {
+                const uint32_t b = (uint32_t)__ffs(todo) - 1u;
+                todo &= todo - 1;
+                const bool odd = (b & 1u) != 0;
+                const uint64_t both = ((uint64_t)(odd ? w1 : w0) << 32) | (odd ? p1 : p0);
+                const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u)); // window d = (b >> 1) + 1 starts 2 d bits in
+                const uint32_t h = key ^ (key >> 13); // dense_bloom_index(key) = h & (2^20 - 1): word h >> 5, bit h & 31
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + ((h >> 3) & 0x1FFFCu));
+                pm |= __builtin_amdgcn_ubfe(word, h, 1) << b;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < (pair ? 2 : 1); ++u) {
+#pragma unroll
+                for (int d = S; d <= 16; d += S) {
+                    const uint32_t wu = u ? w1 : w0, pu = u ? p1 : p0;
+                    const uint32_t key = (d == 16 ? wu : alignbit(wu, pu, (2 * d) & 31)) & kmask;
+                    const uint32_t h = key ^ (key >> 13);
+                    const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds) + ((h >> 3) & 0x1FFFCu));
+                    pm |= __builtin_amdgcn_ubfe(word, h, 1) << (2 * (d - 1) + u);
+                }
+            }
         }
         // level 1b: those that do wait in the queue until the wave has a batch of them (wave-wide steps from here on)
         if (P.dense_debug & 1u)
@@ -714,7 +732,7 @@ __device__ __forceinline__ void dense_group(const filter_params &P, const uint4 
             pm &= pm - 1;
             const bool odd = (b & 1u) != 0;
             const uint64_t both = ((uint64_t)(odd ? w1 : w0) << 32) | (odd ? p1 : p0);
-            const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u));
+            const uint32_t key = (uint32_t)(both >> ((b & ~1u) + 2u)) & kmask;
             const uint64_t mm = __ballot(pos);
             if (pos) {
                 const uint32_t q = qn + __popcll(mm & ((1ull << lane) - 1));
@@ -730,7 +748,7 @@ __device__ __forceinline__ void dense_group(const filter_params &P, const uint4 
     }
 }
 
-template <int U, int NP>
+template <int U, int NP, int S = 0, bool KM = false>
 __global__ __launch_bounds__(1024) void seed_filter_dense_kernel(const filter_params P)
 {
     extern __shared__ uint32_t lds[];
@@ -816,13 +834,13 @@ __global__ __launch_bounds__(1024) void seed_filter_dense_kernel(const filter_pa
                 for (int u = 0; u < U; ++u)
                     nxt[u] = load16_stream<true>(lane_text + pf * 1024 + (uint64_t)u * ustride);
                 __builtin_amdgcn_sched_barrier(0); // the prefetch stays ahead of the group's work
-                dense_group<U, NP>(P, cur, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
+                dense_group<U, NP, S, KM>(P, cur, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
             }
         }
         for (; ch < c_end; ++ch) { // ragged end
             uint4 one[1];
             one[0] = load_text16(P.text, base0 + ch * 1024 + (uint64_t)lane * 16, P.hi);
-            dense_group<1, NP>(P, one, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
+            dense_group<1, NP, S, KM>(P, one, base0 + ch * 1024, span_base, carry_in, lane, lds, Q, qn);
         }
         dense_drain(P, Q, qn, true, span_base, lane, lds); // (offsets in the queue are relative to this span)
         sp += n_waves;

@@ -54,6 +54,7 @@ struct index_tuning
     int dense_max_density = 8; // a set that needs more than this many sixteenths keeps its sparse passes (dense = 2: no limit)
     int dense_cmax = 4;     // pieces of a needle may overlap up to this many deep (c k + 1 pieces then)
     int dense_sweeps = 2;   // rounds of key re-selection that make needles share presence bits (0: first-fit keys)
+    int sparse_bits = 1;    // sparse passes of stride 1 / 2 over dna4: presence bits + L2 buckets as level 1 (0: fingerprint table)
     int threads = 0;        // 0: hardware concurrency, at most 16
     static index_tuning from_env()
     {
@@ -73,6 +74,7 @@ struct index_tuning
         T.dense_max_density = std::max(2, std::min(16, env_int("SPM_HIP_FILTER_DENSE_MAX_DENSITY", 8)));
         T.dense_cmax = std::max(1, std::min(8, env_int("SPM_HIP_FILTER_DENSE_CMAX", 4)));
         T.dense_sweeps = std::max(0, std::min(8, env_int("SPM_HIP_FILTER_DENSE_SWEEPS", 2)));
+        T.sparse_bits = env_int("SPM_HIP_FILTER_BITS", 1);
         T.threads = env_int("SPM_HIP_BUILD_THREADS", 0);
         return T;
     }
@@ -397,6 +399,35 @@ inline void build_directory(std::vector<index_kv> &keys, std::vector<uint16_t> &
     }
 }
 
+// level 1 of a dense pass -- and of sparse passes that look at 8 or 16 windows per 16 symbols, where two LDS reads and two
+// multiplies per window (the fingerprint table) cost more than the pass can hide: one presence bit per key in LDS, then a
+// bucketed fingerprint table in L2 for the windows whose bit is set (filter_shared.hpp)
+inline void build_bits_level1(const std::vector<index_kv> &keys, filter_index &F)
+{
+    F.h_image.assign((1u << kDenseBloomBits) / 32, 0);
+    for (const index_kv &e : keys) {
+        const uint32_t b = dense_bloom_index(e.key);
+        F.h_image[b >> 5] |= 1u << (b & 31);
+    }
+    F.bitmap_words = F.lds_words = (uint32_t)F.h_image.size();
+    uint32_t lg = 12; // about two keys per bucket of kDenseSlots
+    while ((1ull << lg) * 2 < keys.size() && lg < 24)
+        ++lg;
+    F.bucket_shift = 32 - lg;
+    F.h_buckets.assign((size_t)kDenseSlots << lg, 0);
+    for (const index_kv &e : keys) {
+        uint16_t *bk = F.h_buckets.data() + (size_t)dense_bucket(e.key, F.bucket_shift) * kDenseSlots;
+        const uint16_t fp = (uint16_t)dense_fp(e.key);
+        uint32_t s = 0;
+        while (s < kDenseSlots && bk[s] != 0 && bk[s] != fp)
+            ++s;
+        if (s < kDenseSlots)
+            bk[s] = fp;
+        else
+            bk[kDenseSlots - 1] = (uint16_t)kDenseAcceptAll; // overflow: this bucket lets every window through
+    }
+}
+
 inline int build_one_index(const needle_view &nv, const index_tuning &T, const std::vector<seed_key> &items, uint32_t S,
                            filter_index &F, std::vector<u32x4> &entries)
 {
@@ -450,6 +481,14 @@ inline int build_one_index(const needle_view &nv, const index_tuning &T, const s
     F.hash_variant = (uint32_t)T.hash;
     std::vector<uint32_t> &image = F.h_image; // what every workgroup stages into LDS
     image.clear();
+    if (T.sparse_bits != 0 && T.hash == 2 && nv.sigma == 4 && S <= 2 && F.anchor_cm == 0) {
+        // 8 or 16 windows of every 16 symbols are looked up: presence bits (one LDS read, no multiply) + L2 buckets
+        F.hash_variant = 4;
+        build_bits_level1(keys, F);
+        build_directory(keys, ranges, F, entries);
+        F.ok = true;
+        return SPM_OK;
+    }
     if (F.hash_variant == 2) {
         // ---- perfect-hash fingerprint table (hash-and-displace, see filter_shared.hpp) ----
         std::vector<uint32_t> uniq;
@@ -1033,30 +1072,8 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
     F.n_keys = n_keys;
     F.n_entries = n_keys;
     F.hash_variant = 3;
-    // ---- level 1: presence bits ----
-    F.h_image.assign((1u << kDenseBloomBits) / 32, 0);
-    for (const index_kv &e : keys) {
-        const uint32_t b = dense_bloom_index(e.key);
-        F.h_image[b >> 5] |= 1u << (b & 31);
-    }
-    F.bitmap_words = F.lds_words = (uint32_t)F.h_image.size();
-    // ---- level 1b: fingerprint buckets (kDenseSlots per bucket, about two keys per bucket) ----
-    uint32_t lg = 12;
-    while ((1ull << lg) * 2 < n_keys && lg < 24)
-        ++lg;
-    F.bucket_shift = 32 - lg;
-    F.h_buckets.assign((size_t)kDenseSlots << lg, 0);
-    for (const index_kv &e : keys) {
-        uint16_t *bk = F.h_buckets.data() + (size_t)dense_bucket(e.key, F.bucket_shift) * kDenseSlots;
-        const uint16_t fp = (uint16_t)dense_fp(e.key);
-        uint32_t s = 0;
-        while (s < kDenseSlots && bk[s] != 0 && bk[s] != fp)
-            ++s;
-        if (s < kDenseSlots)
-            bk[s] = fp;
-        else
-            bk[kDenseSlots - 1] = (uint16_t)kDenseAcceptAll; // overflow: this bucket lets every window through
-    }
+    // ---- level 1: presence bits; level 1b: fingerprint buckets (kDenseSlots per bucket, about two keys per bucket) ----
+    build_bits_level1(keys, F);
     const double ms_level1 = ms(t2);
     const auto t3 = iclk::now();
     // ---- exact level ----
@@ -1369,7 +1386,7 @@ inline int build_filter_index(const needle_view &nv, const index_tuning &T, seed
         }
         X.filter_max_range = 0;
         for (const filter_index &F : X.fidx) {
-            dense_failure = dense_failure || (want_chd && F.hash_variant != 2);
+            dense_failure = dense_failure || (want_chd && F.hash_variant != 2 && F.hash_variant != 4);
             X.filter_max_range = std::max(X.filter_max_range, F.max_range);
         }
         if (!dense_failure || attempt == 2)
@@ -1415,8 +1432,8 @@ inline int host_selftest(int algo, const uint8_t *ranks_concat, const uint32_t *
     const uint32_t S = ps.filter_stride;
     // level-1 membership test, exactly as the kernels evaluate it
     auto level1 = [&](const filter_index &F, uint32_t key) -> bool {
-        if (F.dense) {
-            if (!((F.dimer_set >> (key & 15u)) & 1u))
+        if (F.dense || F.hash_variant == 4) {
+            if (F.dense && !((F.dimer_set >> (key & 15u)) & 1u))
                 return false; // the streaming kernel does not look this window up
             const uint32_t b = dense_bloom_index(key);
             if (!((F.h_image[b >> 5] >> (b & 31)) & 1u))

@@ -94,7 +94,7 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
             for (filter_index &F : ps->fidx) {
                 SPM_HIP_CHECK(ctx, upload(&F.d_bitmap, F.h_image.data(), F.h_image.size() * sizeof(uint32_t)));
                 SPM_HIP_CHECK(ctx, upload(&F.d_ht, F.h_ht.data(), F.h_ht.size() * sizeof(u32x4)));
-                if (F.dense)
+                if (!F.h_buckets.empty())
                     SPM_HIP_CHECK(ctx, upload(&F.d_buckets, F.h_buckets.data(), F.h_buckets.size() * sizeof(uint16_t)));
                 ps->build.keys += F.n_keys;
                 for (uint32_t d = 0; d < 16; ++d)

@@ -251,7 +251,8 @@ int run_filter(const scan_args &A)
     P.buckets = reinterpret_cast<const uint4 *>(F.d_buckets);
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
-    const bool use_packed = !F.dense && A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
+    const bool bits = F.hash_variant == 4; // presence bits + L2 buckets as level 1 of a sparse pass: the dense kernel's machinery
+    const bool use_packed = !F.dense && !bits && A.text->d_packed && ps->sigma == 4 && F.hash_variant == 2 && F.stride >= 2 &&
                             !(A.opts.flags & SPM_SCAN_IGNORE_PACKED);
     // measured best: 8 waves per CU on the 1-byte text when HBM binds, 16 on the 2-bit shadow and at stride 1 with
     // 16-symbol keys (LDS-bound: C4 25.8 vs 29.1 ms; the other stride-1/2 variants need more than 128 VGPRs)
@@ -260,10 +261,10 @@ int run_filter(const scan_args &A)
     const bool narrow2 = F.stride == 2 && !use_packed && env_int("SPM_HIP_FILTER_S2_U", 2) == 2;
     const bool wide_ok = use_packed || narrow2 || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
                                                    !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
-    const uint32_t threads = F.dense ? 1024u : (uint32_t)std::max(
+    const uint32_t threads = (F.dense || bits) ? 1024u : (uint32_t)std::max(
         64, std::min(wide_ok ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", wide_ok ? 1024 : 512)));
     // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave (+ dense: one queue per wave)
-    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4 + (F.dense ? 16 * sizeof(dense_queue) : 0);
+    const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4 + ((F.dense || bits) ? 16 * sizeof(dense_queue) : 0);
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
@@ -348,7 +349,27 @@ int run_filter(const scan_args &A)
         else                                                                                                           \
             LAUNCH_FILTER2(S, (UMAX >= 4 ? 4 : UMAX));                                                                 \
     } while (0)
-    if (F.dense) {
+    if (bits) {
+#define LAUNCH_BITS(S, KM)                                                                                             \
+    do {                                                                                                               \
+        hipFuncSetAttribute((const void *)seed_filter_dense_kernel<4, 1, S, KM>,                                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        hipLaunchKernelGGL((seed_filter_dense_kernel<4, 1, S, KM>), dim3(grid), dim3(threads), lds, ctx->stream, P);   \
+    } while (0)
+        const bool km = F.key_len < 16;
+        if (F.stride == 1) {
+            if (km)
+                LAUNCH_BITS(1, true);
+            else
+                LAUNCH_BITS(1, false);
+        } else {
+            if (km)
+                LAUNCH_BITS(2, true);
+            else
+                LAUNCH_BITS(2, false);
+        }
+#undef LAUNCH_BITS
+    } else if (F.dense) {
 #define LAUNCH_DENSE(NP)                                                                                               \
     do {                                                                                                               \
         hipFuncSetAttribute((const void *)seed_filter_dense_kernel<4, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, \

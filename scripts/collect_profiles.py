@@ -11,7 +11,7 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", f"prof_{tag}"), os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
@@ -43,32 +43,73 @@ for w in ("c3", "c2", "c4", "c5", "c3r", "reads100"):
                 if sum(v) > 0.02:
                     g.write(f"{k[:70]:70s} n={len(v):3d}  " + " ".join(f"{x:.3f}" for x in v[-12:]) + "\n")
 # SQ counters per kernel (two passes each)
-for w in ("c3", "c4", "c5"):
+for w in ("c3", "c4", "c5", "c3r"):
+    if not os.path.isdir(f"{src}/pmc1_{w}"):
+        continue
     out = subprocess.run([sys.executable, "scripts/summarise_pmc.py", f"{src}/pmc1_{w}", f"{src}/pmc2_{w}"],
                          capture_output=True, text=True).stdout
     out = out.replace(os.path.abspath(src), f"gpurun_out/prof_{tag}")
     open(f"{dst}/{w}_pmc_SQ.txt", "w").write(out)
-# HBM traffic of the C3 streaming kernel: FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE, KB units
-vals = {}
-for name in ("fetch", "write"):
-    f = newest(f"{src}/pmc_{name}_c3/**/*_counter_collection.csv")
-    rows = [r for r in csv.DictReader(open(f)) if "seed_filter" in r["Kernel_Name"]]
-    with open(f"{dst}/c3_pmc_{name.upper()}_SIZE.csv", "w") as g:
-        wr = csv.writer(g)
-        wr.writerow(["kernel", "counter", "value_KB", "duration_ns"])
-        for r in rows:
-            wr.writerow([short(r["Kernel_Name"]), r["Counter_Name"], r["Counter_Value"],
-                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
-    v = [float(r["Counter_Value"]) for r in rows]
-    vals[name] = sum(v) / len(v)
-traffic = vals["fetch"] * 1024 * 2 + vals["write"] * 1024
-json.dump({"c3": {"text_bytes_per_gpu": 17179869184, "kernel": "seed_filter_kernel",
-                  "FETCH_SIZE_KB": vals["fetch"], "WRITE_SIZE_KB": vals["write"], "hbm_bytes_per_launch": traffic,
-                  "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-                            f"(profiles/{tag}/c3_pmc_*_SIZE.csv); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
-                            "tallies the 128-B requests of a 16 B/lane stream at 64 B), WRITE_SIZE as read"}},
-          open("profiles/pmc_traffic.json", "w"), indent=1)
-print("traffic / algorithmic =", traffic / 17179869184)
+# HBM traffic of every config: FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE, KB units, separate passes.
+#   per launch of the dominant (streaming) kernel  -> roofline.traffic, comparable with roofline.achieved
+#   per step, all kernels of one scan              -> what resolve / verification / hit copies add
+MAIN = {"c3": "seed_filter_kernel", "c2": "seed_filter_kernel", "c4": "seed_filter_dense_kernel", "c5": "seed_filter_kernel",
+        "c3r": "seed_filter_kernel", "reads100": "seed_filter_dense_kernel"}
+SETUP = ("synth_", "jst_dedupe", "jst_emit", "jst_chunk", "jst_delta", "jst_start", "jst_alo", "jst_widen", "vectorized_elementwise",
+         "text_validate", "text_pack", "rocprim", "hipcub")
+traffic_all = {}
+try:
+    bench = json.loads(open(f"{src}/bench_default.json").read().strip().splitlines()[-1])
+except Exception:
+    bench = None
+for w, main in MAIN.items():
+    per = {}
+    for name in ("fetch", "write"):
+        f = newest(f"{src}/pmc_{name}_{w}/**/*_counter_collection.csv")
+        if not f:
+            per = None
+            break
+        rows = list(csv.DictReader(open(f)))
+        mains = [r for r in rows if main in r["Kernel_Name"]]
+        with open(f"{dst}/{w}_pmc_{name.upper()}_SIZE.csv", "w") as g:
+            wr = csv.writer(g)
+            wr.writerow(["kernel", "counter", "value_KB", "duration_ns"])
+            for r in rows:
+                if not any(x in r["Kernel_Name"] for x in SETUP):
+                    wr.writerow([short(r["Kernel_Name"]), r["Counter_Name"], r["Counter_Value"],
+                                 int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+        if not mains:
+            per = None
+            break
+        # the launches of full scans only (the last ones: warm-up scans of a fresh needle set may repeat a launch)
+        mv = [float(r["Counter_Value"]) for r in mains][-2:]
+        per[name] = sum(mv) / len(mv)
+        # every kernel of one step: everything between the last two launches of the main kernel (exclusive of set-up kernels)
+        idx = [i for i, r in enumerate(rows) if main in r["Kernel_Name"]]
+        lo, hi = idx[-2], idx[-1]
+        per[name + "_step"] = sum(float(r["Counter_Value"]) for r in rows[lo:hi] if not any(x in r["Kernel_Name"] for x in SETUP))
+    if not per:
+        continue
+    launch = per["fetch"] * 1024 * 2 + per["write"] * 1024
+    step = per["fetch_step"] * 1024 * 2 + per["write_step"] * 1024
+    entry = {"kernel": main, "FETCH_SIZE_KB": per["fetch"], "WRITE_SIZE_KB": per["write"], "hbm_bytes_per_launch": launch,
+             "hbm_bytes_per_step_all_kernels": step,
+             "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/{tag}/{w}_pmc_*_SIZE.csv); "
+                       "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of a 16 B/lane stream at "
+                       "64 B), WRITE_SIZE as read; per launch of the streaming kernel, and summed over every kernel of one step"}
+    alg = None
+    if bench is not None:
+        o = bench if w == "c3" else bench.get("other_configs", {}).get(w)
+        if o and "roofline" in o:
+            alg = o["roofline"].get("algorithmic_bytes_per_launch")
+    if alg:
+        entry["algorithmic_bytes_per_launch"] = alg
+        entry["text_bytes_per_gpu"] = alg
+        entry["traffic_over_algorithmic"] = launch / alg
+        entry["step_traffic_over_algorithmic"] = step / alg
+    traffic_all[w] = entry
+    print(w, "traffic / algorithmic per launch =", round(launch / alg, 4) if alg else None, " per step =", round(step / alg, 4) if alg else None)
+json.dump(traffic_all, open("profiles/pmc_traffic.json", "w"), indent=1)
 # the repeat sweep
 rows = []
 for f in sorted(glob.glob(f"{src}/c3r_f*_e*.json")):
@@ -84,7 +125,7 @@ with open(f"{dst}/c3r_sweep.md", "w") as g:
         g.write(f"| {frac:g} | {forced} of {r['config']['needles']} | {r['value']:.0f} | {r['ms_per_step']:.2f} | "
                 f"{r['roofline']['kernel_ms']:.2f} | {r['candidates']} | {r['bands_verified']} | {r['hits']} | "
                 f"{r['fallback_spans']} |\n")
-for f in ("hbm_read_probe.log",):
+for f in ("hbm_read_probe.log", "l2_gather_probe.log"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{f}")
 print(open(f"{dst}/c3r_sweep.md").read())

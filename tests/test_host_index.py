@@ -44,6 +44,7 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     big = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(6000)]
     rc, st = _selftest(spm, spm.ALGO_MYERS, big, 3)
     assert rc == 0 and st["missing"] == 0 and st["passes"] == 1 and st["stride"] == 2 and st["keys"] == 6000 * 4 * 2
+    assert st["hash_variant"] == 4      # 8 windows of every 16 symbols are looked up: presence bits + L2 buckets as level 1
     # 20 000 needles: 80 000 seeds do not fit one table (57 344 keys) even at stride 1.  Sparse passes: sub-batches; the
     # cost model prefers three passes at stride 2 to two at stride 1.  (By default such a set takes the dense pass, below.)
     big20 = big + [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(14000)]
@@ -52,7 +53,7 @@ def test_exact_and_long_needles_and_sub_batches(spm):
     try:
         rc, st = _selftest(spm, spm.ALGO_MYERS, big20, 3)
         assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (3, 2, 160000)
-        assert st["hash_variant"] == 2
+        assert st["hash_variant"] == 4      # stride 2: presence bits (stride >= 4 and anchored passes: fingerprint table)
         # a C4-sized set: 400 000 seeds at stride 1, one key per seed.  Anchored: every seed's key begins with the dimer of
         # its pass (the streaming kernel looks up only the text windows that begin with it); a few passes take two dimers
         rc, st = _selftest(spm, spm.ALGO_MYERS, c4, 3)
@@ -64,7 +65,7 @@ def test_exact_and_long_needles_and_sub_batches(spm):
         finally:
             del os.environ["SPM_HIP_FILTER_ANCHOR"]
         assert rc == 0 and st["missing"] == 0 and (st["passes"], st["stride"], st["keys"]) == (7, 1, 400000)
-        assert st["hash_variant"] == 2 and st["anchor_dimers"] == 0
+        assert st["hash_variant"] == 4 and st["anchor_dimers"] == 0
     finally:
         del os.environ["SPM_HIP_FILTER_DENSE"]
     # mixed lengths and k: the stride follows the shortest seed
@@ -164,8 +165,8 @@ def test_dense_pass_index(spm):
     os.environ["SPM_HIP_FILTER_DENSE"] = "2"
     try:
         rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 60, dtype=np.uint8) for _ in range(100)], 3)
-        assert rc == 0 and st["hash_variant"] == 2
+        assert rc == 0 and st["hash_variant"] == 4 and st["stride"] == 2     # (a sparse pass; stride 2: presence bits)
         rc, st = _selftest(spm, spm.ALGO_MYERS, [rng.integers(0, 4, 1024, dtype=np.uint8) for _ in range(8)], 64)
-        assert rc == 0 and st["hash_variant"] == 2
+        assert rc == 0 and st["hash_variant"] == 4 and st["stride"] == 2
     finally:
         del os.environ["SPM_HIP_FILTER_DENSE"]
