@@ -577,10 +577,14 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     hit_buf = xp.new_buffer(dev)
 
     def step():
+        # SCAN_DEFER: a scan that cannot need a second attempt on the device side alone (exact sets: C2) returns once its
+        # kernels are enqueued; with the device-side fused copy the step then has no host synchronisation at all, and its
+        # statistics are read one step later (below) -- the GPU never waits for the host between steps
         h = S.scan(ctx, text, ps, sp.scan_begin, sp.scan_end, engine=engine, left_context=True,
-                   pos_offset=sp.pos_offset, max_hits=max_hits)
+                   pos_offset=sp.pos_offset, max_hits=max_hits, flags=S.SCAN_DEFER if fused else 0)
         if fused:
-            n = h.copy_fused(hit_buf.data_ptr(), cap)        # [count | records], on the scan's stream
+            h.copy_fused_device(hit_buf.data_ptr(), cap)     # [count, status | records], written on the device
+            n = 0
         else:
             n = h.copy_to(hit_buf[1:].data_ptr(), cap)      # records (D2D on this stream)
         return h, xp.exchange(hit_buf, n)                    # N > 1: the collective; N = 1: a view
@@ -604,14 +608,18 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     ms_main = ms_verify = 0.0
     launches = 0
     last = None
-    for _ in range(args.steps):
-        h, g = step()
-        st = h.stats()
-        ms_main += st.ms_main
-        ms_verify += st.ms_verify
-        launches += st.main_launches
-        last = (st, g)
-        h.close()
+    prev = None
+    for _ in range(args.steps + 1):
+        cur = step() if _ < args.steps else None
+        if prev is not None:            # the step before: its kernels are done or running behind this step's
+            h, g = prev
+            st = h.stats()
+            ms_main += st.ms_main
+            ms_verify += st.ms_verify
+            launches += st.main_launches
+            last = (st, g)
+            h.close()
+        prev = cur
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

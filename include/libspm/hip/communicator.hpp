@@ -53,16 +53,30 @@ public:
         return {lo, std::min<std::uint64_t>(n, lo + per)};
     }
 
-    // every rank's hits on `root`, rank order = ascending shard order (per shard: arrival order); empty elsewhere
-    std::vector<spm_hit> gatherv(spm_hits * local, int root = 0) const noexcept
+    // every rank's hits on `root`, rank order = ascending shard order (per shard: arrival order); empty elsewhere.
+    // Failure is collective (include/spm_hip.h): if any rank cannot contribute -- its scan overflowed its hit buffer, the
+    // root cannot hold the records -- EVERY rank gets a status back (the failing rank its own, the others SPM_E_PEER)
+    // and nothing was sent; no rank is left waiting in a collective.
+    int try_gatherv(spm_hits * local, std::vector<spm_hit> & out, int root = 0) const noexcept
     {
         void const * d = nullptr;
         std::uint64_t n = 0;
-        if (spm_hip_gatherv_hits(_comm, local, root, &d, &n, nullptr) != SPM_OK)
-            fatal("spm_hip_gatherv_hits", default_context());
-        std::vector<spm_hit> out(n);
+        out.clear();
+        int const rc = spm_hip_gatherv_hits(_comm, local, root, &d, &n, nullptr);
+        if (rc != SPM_OK)
+            return rc;
+        out.resize(n);
         if (n && hipMemcpy(out.data(), d, n * sizeof(spm_hit), hipMemcpyDeviceToHost) != hipSuccess)
-            fatal("hipMemcpy (gathered hits)", default_context());
+            return SPM_E_HIP;
+        return SPM_OK;
+    }
+
+    // the same for callers that treat any failure as fatal (the noexcept style of the matcher call operators)
+    std::vector<spm_hit> gatherv(spm_hits * local, int root = 0) const noexcept
+    {
+        std::vector<spm_hit> out;
+        if (try_gatherv(local, out, root) != SPM_OK)
+            fatal("spm_hip_gatherv_hits", default_context());
         return out;
     }
 };

@@ -83,6 +83,15 @@ typedef struct spm_scan_opts {
 } spm_scan_opts;
 
 #define SPM_SCAN_IGNORE_PACKED 1u /* do not use the text's 2-bit shadow even if it has one */
+/* Deferred completion.  spm_hip_scan normally returns when it KNOWS the scan is complete: it reads the device counters
+ * back once (one host synchronisation), because a list that proved too small means another attempt.  With this flag the
+ * call returns as soon as the kernels are enqueued whenever the scan cannot need a second attempt on the device side
+ * alone -- today: exact needle sets whose hits come straight from the resolve kernel (Shift-Or / Horspool sets, config
+ * C2) --; the counters are read at the first accessor that needs the hit count (view, device, copy_device, copy_fused,
+ * stats, destroy), and a scan that does need attention is repeated there, synchronously.  The text and the needle set
+ * must stay alive until then.  Other scans ignore the flag.  With spm_hip_hits_copy_fused_device a step of a scan loop
+ * has no host synchronisation at all: the GPU never waits for the host between steps. */
+#define SPM_SCAN_DEFER 2u
 
 /* Per-scan device timings, HIP events on the context's stream (ms). */
 typedef struct spm_scan_stats {
@@ -204,6 +213,11 @@ int spm_hip_hits_copy_device(spm_hits *hits, void *device_dst, uint64_t cap, uin
  * This is the fixed-size [count | records] buffer one ncclAllGather per scan exchanges (libspm_amd.dist.gather_hits_fused):
  * the count is written from the host value the library already has, no second call from the caller. */
 int spm_hip_hits_copy_fused(spm_hits *hits, void *device_dst, uint64_t cap, uint64_t *n);
+/* The same without the host knowing the count: a kernel reads the scan's counters on the device and writes the header
+ * {n as uint64, status as uint64} and the first min(n, cap) records.  status 0: the records are the scan's final result;
+ * nonzero: the scan needs the host's attention (a list overflowed, spans gave up) -- call an accessor (which completes
+ * the scan) and copy again.  Does not synchronise; completes nothing. */
+int spm_hip_hits_copy_fused_device(spm_hits *hits, void *device_dst, uint64_t cap);
 int spm_hip_hits_stats(const spm_hits *hits, spm_scan_stats *out);
 /* order-independent checksum: sum over hits of mix64(pos ^ pattern<<40 ^ score<<58), SURVEY.md 8(d) */
 uint64_t spm_hip_hits_checksum(spm_hits *hits);

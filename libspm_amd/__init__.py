@@ -6,7 +6,7 @@ header-only API is in include/libspm/.
 """
 from . import capi  # noqa: F401
 from .capi import (ALGO_HORSPOOL, ALGO_MYERS, ALGO_MYERS_PREFIX, ALGO_SHIFTOR, ENGINE_AUTO, ENGINE_BRUTE,  # noqa: F401
-                   ENGINE_FILTER, SpmError)
+                   ENGINE_FILTER, SCAN_DEFER, SCAN_IGNORE_PACKED, SpmError)
 from .engine import (ALLELE_DTYPE, HIT_DTYPE, JST_HIT_DTYPE, Context, Hits, Jst, JstHits, PatternSet, Text, scan, scan_segments,
                      synth_variants,  # noqa: F401
                      synth_pattern, synth_repeat_pattern, synth_repeat_text)

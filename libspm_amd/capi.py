@@ -15,6 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 ALGO_SHIFTOR, ALGO_MYERS, ALGO_MYERS_PREFIX, ALGO_HORSPOOL = 0, 1, 2, 3
 ENGINE_AUTO, ENGINE_BRUTE, ENGINE_FILTER = 0, 1, 2
 SCAN_IGNORE_PACKED = 1
+SCAN_DEFER = 2
 MAX_NEEDLE = 2048
 
 
@@ -154,6 +155,7 @@ def lib():
         "spm_hip_hits_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "spm_hip_hits_copy_device": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
         "spm_hip_hits_copy_fused": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "spm_hip_hits_copy_fused_device": (C.c_int, [vp, vp, C.c_uint64]),
         "spm_hip_hits_stats": (C.c_int, [vp, C.POINTER(ScanStats)]),
         "spm_hip_hits_checksum": (C.c_uint64, [vp]),
         "spm_hip_hits_destroy": (None, [vp]),
@@ -204,7 +206,7 @@ EXPORTS = [
     "spm_hip_text_device_ptr", "spm_hip_text_destroy", "spm_hip_patterns_create", "spm_hip_patterns_destroy",
     "spm_hip_patterns_window_size", "spm_hip_patterns_filterable", "spm_hip_patterns_build_stats", "spm_hip_patterns_state_stride",
     "spm_hip_patterns_state_init", "spm_hip_scan", "spm_hip_scan_segments", "spm_hip_hits_view", "spm_hip_hits_device",
-    "spm_hip_hits_copy_device", "spm_hip_hits_copy_fused", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
+    "spm_hip_hits_copy_device", "spm_hip_hits_copy_fused", "spm_hip_hits_copy_fused_device", "spm_hip_hits_stats", "spm_hip_hits_checksum", "spm_hip_hits_destroy", "spm_hip_synth_pattern",
     "spm_hip_synth_repeat_pattern", "spm_hip_synth_repeat_text", "spm_hip_mix64", "spm_hip_host_selftest", "spm_hip_version",
     "spm_hip_jst_create", "spm_hip_jst_destroy", "spm_hip_jst_haplotype_length", "spm_hip_jst_extract",
     "spm_hip_jst_index", "spm_hip_jst_search", "spm_hip_jst_stats", "spm_hip_jst_hits_view", "spm_hip_jst_hits_device",

@@ -33,6 +33,8 @@ struct hits_block // device buffers + events of one scan result, recycled throug
     uint64_t cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool zeroed = false; // the counters were cleared when the block went back to the pool
+    unsigned long long *h_c = nullptr; // pinned: where a deferred scan's counters land (allocated on first use, recycled)
+    hipEvent_t ev_done = nullptr;
 };
 
 struct spm_ctx
@@ -85,6 +87,15 @@ struct spm_hits
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     void *d_aux[2] = {nullptr, nullptr}; // segmented scans: tile table, segment offsets (freed with the hits)
+    // deferred completion (SPM_SCAN_DEFER): the counters are on their way to h_c behind ev_done; what the scan was, in case
+    // it has to be repeated
+    bool pending = false;
+    unsigned long long *h_c = nullptr;
+    hipEvent_t ev_done = nullptr;
+    const spm_text *d_text = nullptr;
+    const struct spm_patterns *d_patterns = nullptr;
+    uint64_t d_begin = 0, d_end = 0;
+    spm_scan_opts d_opts{};
 };
 
 struct pass_entry // key directory of one pass of the seed filter, in L2 (filter.hpp: resolve_kernel)

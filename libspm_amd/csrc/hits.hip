@@ -9,6 +9,11 @@
 static int hits_count(spm_hits *h)
 {
     spm_ctx *ctx = h->ctx;
+    if (h->pending) {
+        const int rc = spm_complete_deferred(h);
+        if (rc != SPM_OK)
+            return rc;
+    }
     if (!h->counted) {
         unsigned long long *c = ctx->h_counters;
         SPM_HIP_CHECK(ctx, hipMemcpyAsync(c, h->d_count, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -110,6 +115,45 @@ extern "C" int spm_hip_hits_copy_fused(spm_hits *h, void *device_dst, uint64_t c
     return SPM_OK;
 }
 
+// [count | status | records] without the host: the counters are read on the device.  status != 0: a list overflowed or
+// spans gave up -- the host has to complete the scan (scan.hip: spm_complete_deferred).
+__global__ __launch_bounds__(256) void hits_fused_copy_device_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src,
+                                                                       const unsigned long long *__restrict__ counters,
+                                                                       unsigned long long cap, unsigned long long hit_cap,
+                                                                       unsigned long long cand_cap)
+{
+    const unsigned long long n = counters[0];
+    const unsigned long long status = (counters[2] != 0 || counters[6] != 0 || counters[1] > cand_cap || n > hit_cap) ? 1ull : 0ull;
+    const unsigned long long n_copy = n < cap ? (n < hit_cap ? n : hit_cap) : cap;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        dst[0] = make_uint4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)status, 0u);
+    for (uint64_t r = i; r < n_copy; r += (uint64_t)gridDim.x * blockDim.x)
+        dst[1 + r] = src[r];
+}
+
+extern "C" int spm_hip_hits_copy_fused_device(spm_hits *h, void *device_dst, uint64_t cap)
+{
+    if (!h || !device_dst || ((uintptr_t)device_dst & 15))
+        return SPM_E_INVALID;
+    if (!h->pending && h->counted) {
+        // the host has completed this scan (its fallbacks included; the device counters may still show what it handled):
+        // the count it knows, status 0
+        const uint64_t c = std::min(h->n, std::min<uint64_t>(cap, h->cap));
+        const unsigned g1 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((c + 255) / 256, (uint64_t)h->ctx->n_cu * 4));
+        hipLaunchKernelGGL(hits_fused_copy_kernel, dim3(g1), dim3(256), 0, h->ctx->stream, static_cast<uint4 *>(device_dst),
+                           reinterpret_cast<const uint4 *>(h->d_hits), (unsigned long long)h->n, (unsigned long long)c);
+        SPM_HIP_CHECK(h->ctx, hipGetLastError());
+        return SPM_OK;
+    }
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((std::min<uint64_t>(cap, h->cap) + 255) / 256, (uint64_t)h->ctx->n_cu));
+    hipLaunchKernelGGL(hits_fused_copy_device_kernel, dim3(grid), dim3(256), 0, h->ctx->stream, static_cast<uint4 *>(device_dst),
+                       reinterpret_cast<const uint4 *>(h->d_hits), h->d_count, (unsigned long long)cap,
+                       (unsigned long long)h->cap, (unsigned long long)(h->cand_cap ? h->cand_cap : ~0ull));
+    SPM_HIP_CHECK(h->ctx, hipGetLastError());
+    return SPM_OK;
+}
+
 extern "C" int spm_hip_hits_stats(const spm_hits *hc, spm_scan_stats *out)
 {
     if (!hc || !out)
@@ -145,6 +189,8 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
 {
     if (!h)
         return;
+    if (h->pending)
+        (void)spm_complete_deferred(h); // (the needle set's hints; a scan that needed attention is simply dropped here)
     if (h->d_aux[0] || h->d_aux[1]) {
         if (h->ctx)
             hipStreamSynchronize(h->ctx->stream);
@@ -158,6 +204,8 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
         b.cap = h->cap;
         for (int e = 0; e < 4; ++e)
             b.ev[e] = h->ev[e];
+        b.h_c = h->h_c;
+        b.ev_done = h->ev_done;
         // the next scan's counters: cleared now, behind this scan's last read of them (stream order), not in front of that scan
         b.zeroed = hipMemsetAsync(b.d_count, 0, 16 * sizeof(unsigned long long), h->ctx->stream) == hipSuccess;
         h->ctx->pool.push_back(b); // stream order makes reuse by the next scan safe
@@ -169,6 +217,10 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
         for (int i = 0; i < 6; ++i)
             if (h->ev[i])
                 hipEventDestroy(h->ev[i]);
+        if (h->h_c)
+            hipHostFree(h->h_c);
+        if (h->ev_done)
+            hipEventDestroy(h->ev_done);
     }
     delete h;
 }

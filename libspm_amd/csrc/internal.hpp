@@ -87,6 +87,7 @@ struct scan_args
     bool seen_full = false;                  // retry after a dedupe-set overflow: size it for the caller's hit buffer
     bool need_seen = false;                  // exact sets reporting from the resolve kernel: the dedupe set after all (spans gave up)
     bool seen_skipped = false;               // ... this run went without it
+    bool exact_used = false;                 // this run reported its hits from the resolve kernel (no bands, no verification)
     std::vector<uint64_t> seg_host;          // host copy fetched on demand when only the device table was given
     // span-local fallback: the filter run leaves these for the brute-force re-scan of the spans that gave up
     unsigned long long *d_seen = nullptr;
@@ -124,3 +125,6 @@ void spm_warm_brute_kernels();
 void spm_warm_filter_kernels();
 void spm_warm_hits_kernels();
 void spm_warm_jst_kernels();
+
+// deferred scans (SPM_SCAN_DEFER): read the counters back, and repeat the scan if it needs attention   (scan.hip)
+int spm_complete_deferred(spm_hits *h);

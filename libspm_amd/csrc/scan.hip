@@ -80,6 +80,8 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
                 ctx->pool.erase(ctx->pool.begin() + i);
                 H->d_hits = b.d_hits;
                 H->d_count = b.d_count;
+                H->h_c = b.h_c;
+                H->ev_done = b.ev_done;
                 for (int e = 0; e < 4; ++e)
                     H->ev[e] = b.ev[e];
                 reused = true;
@@ -155,6 +157,24 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
+            if ((opts.flags & SPM_SCAN_DEFER) && A.exact_used && outer == 0 && attempt == 0 && !stateful && !segmented &&
+                !after_launch) {
+                // deferred completion: the counters travel to this result's own pinned block; nobody waits for them now
+                if (!H->h_c)
+                    SPM_HIP_CHECK(ctx, hipHostMalloc(&H->h_c, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+                if (!H->ev_done)
+                    SPM_HIP_CHECK(ctx, hipEventCreateWithFlags(&H->ev_done, hipEventDisableTiming));
+                SPM_HIP_CHECK(ctx, hipMemcpyAsync(H->h_c, H->d_count, 13 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+                SPM_HIP_CHECK(ctx, hipEventRecord(H->ev_done, ctx->stream));
+                H->pending = true;
+                H->d_text = text;
+                H->d_patterns = patterns;
+                H->d_begin = begin;
+                H->d_end = end;
+                H->d_opts = opts;
+                *out = H.release();
+                return SPM_OK;
+            }
             if (after_launch && !stateful) {
                 rc = (*after_launch)(H.get());
                 if (rc != SPM_OK)
@@ -425,3 +445,53 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
     return SPM_OK;
 }
 
+
+// A deferred scan's counters have arrived (or are waited for here).  The usual case: nothing overflowed, no span gave up --
+// the hit list is final.  Otherwise the scan is repeated the ordinary way (with its retries and fallbacks) and its result
+// takes this one's place.
+int spm_complete_deferred(spm_hits *h)
+{
+    if (!h->pending)
+        return SPM_OK;
+    spm_ctx *ctx = h->ctx;
+    h->pending = false;
+    SPM_HIP_CHECK(ctx, hipEventSynchronize(h->ev_done));
+    const unsigned long long *c = h->h_c;
+    h->stats.n_candidates = c[5];
+    h->stats.n_bands = (uint32_t)std::min<unsigned long long>(c[7], 0xFFFFFFFFull);
+    const bool clean = c[2] == 0 && c[6] == 0 && c[1] <= h->cand_cap;
+    if (clean || c[0] > h->cap) { // (more hits than the buffer takes is the caller's overflow, not a reason to scan again)
+        if (clean) {
+            const spm_patterns *ps = h->d_patterns;
+            ps->cand_hint = std::max<uint64_t>(ps->cand_hint, c[1]);
+            ps->hit_hint = std::max<uint64_t>(ps->hit_hint, c[0]);
+            ps->scanned = true;
+        }
+        h->n = c[0];
+        h->counted = true;
+        return SPM_OK;
+    }
+    spm_scan_opts o = h->d_opts;
+    o.flags &= ~SPM_SCAN_DEFER;
+    spm_hits *again = nullptr;
+    const int rc = scan_impl(ctx, h->d_text, h->d_begin, h->d_end, h->d_patterns, &o, nullptr, nullptr, nullptr, 0, &again);
+    if (rc != SPM_OK)
+        return rc;
+    std::swap(h->d_hits, again->d_hits);
+    std::swap(h->d_count, again->d_count);
+    std::swap(h->cap, again->cap);
+    for (int e = 0; e < 6; ++e)
+        std::swap(h->ev[e], again->ev[e]);
+    std::swap(h->d_aux[0], again->d_aux[0]);
+    std::swap(h->d_aux[1], again->d_aux[1]);
+    h->n = again->n;
+    h->counted = again->counted;
+    h->stats = again->stats;
+    h->cand_cap = again->cand_cap;
+    h->band_cap = again->band_cap;
+    h->timed = again->timed;
+    h->sorted_host = false;
+    h->host.clear();
+    spm_hip_hits_destroy(again);
+    return SPM_OK;
+}

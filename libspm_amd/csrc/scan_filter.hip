@@ -208,6 +208,7 @@ int run_filter(const scan_args &A)
     // re-scan of that span would report its hits a second time): then the scan runs again with the set.
     const bool skip_seen = exact_hits && !A.need_seen && env_int("SPM_HIP_EXACT_SKIP_DEDUPE", 1) != 0;
     const_cast<scan_args &>(A).seen_skipped = skip_seen;
+    const_cast<scan_args &>(A).exact_used = exact_hits;
     if (!skip_seen)
         SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
     if (!exact_hits)

@@ -84,6 +84,10 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
         for (int e = 0; e < 4; ++e)
             if (b.ev[e])
                 hipEventDestroy(b.ev[e]);
+        if (b.h_c)
+            hipHostFree(b.h_c);
+        if (b.ev_done)
+            hipEventDestroy(b.ev_done);
     }
     for (auto &b : ctx->jst_pool)
         hipFree(b.first);

@@ -213,7 +213,11 @@ def gather_hits_fused(buf: torch.Tensor, group=None):
 def split_fused(gathered: torch.Tensor) -> torch.Tensor:
     """Root side of gather_hits_fused: concatenation of every rank's records in rank (= shard) order."""
     cap = gathered.shape[1] - 1
-    counts = gathered[:, 0, 0].cpu().tolist()
+    head = gathered[:, 0, :].cpu()
+    counts = head[:, 0].tolist()
+    if any(int(s) != 0 for s in head[:, 1].tolist()):
+        # (spm_hip_hits_copy_fused_device: the header's second word says the scan needs its host -- a list overflowed)
+        raise RuntimeError("a rank's fused buffer holds an unfinished scan: complete it (Hits.view / stats) and copy again")
     if any(c > cap for c in counts):
         raise OverflowError(f"a rank produced {max(counts)} hits but the fused gather buffer holds {cap}")
     return torch.cat([gathered[r, 1:1 + int(c)] for r, c in enumerate(counts)]) if counts else gathered[0, 1:1]

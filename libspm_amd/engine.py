@@ -200,6 +200,11 @@ class Hits:
         _check(capi.lib().spm_hip_hits_copy_fused(self._h, C.c_void_p(device_ptr), cap, C.byref(n)), self.ctx._h)
         return int(n.value)
 
+    def copy_fused_device(self, device_ptr: int, cap: int) -> None:
+        """copy_fused without the host knowing the count: header {count, status} written by a kernel from the scan's device
+        counters (status != 0: the scan needs the host -- call view() / stats() and copy again).  No synchronisation."""
+        _check(capi.lib().spm_hip_hits_copy_fused_device(self._h, C.c_void_p(device_ptr), cap), self.ctx._h)
+
     def stats(self) -> capi.ScanStats:
         s = capi.ScanStats()
         _check(capi.lib().spm_hip_hits_stats(self._h, C.byref(s)), self.ctx._h)

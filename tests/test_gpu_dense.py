@@ -206,3 +206,56 @@ def test_dense_restorable_chunks(spm, ctx):
     assert np.array_equal(res[spm.ENGINE_FILTER][1], res[spm.ENGINE_BRUTE][1])
     whole = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
     assert np.array_equal(res[spm.ENGINE_BRUTE][0], whole)
+
+
+def test_deferred_completion_of_exact_scans(spm, ctx):
+    """SPM_SCAN_DEFER: an exact-set scan returns once its kernels are enqueued; the counters are read at the first accessor.
+    The device-side fused copy writes {count, status | records} without the host.  A scan that needs attention (spans gave
+    up) says so in the status word and is repeated, synchronously, when the host looks at it."""
+    import torch
+    rng = np.random.default_rng(41)
+    n = 1 << 22
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    needles = [T[a:a + 32].copy() for a in rng.integers(0, n - 32, 512)]
+    text = ctx.upload(T)
+    ps = ctx.patterns(spm.ALGO_SHIFTOR, needles, k=0)
+    want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
+    assert len(want) >= 512
+    cap = 4096
+    buf = torch.zeros((cap + 1, 2), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+    for _ in range(3):
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
+        h.copy_fused_device(buf.data_ptr(), cap)
+        ctx.synchronize()
+        stream.synchronize()
+        head = buf[0].cpu().tolist()
+        assert head == [len(want), 0]
+        rec = buf[1:1 + len(want)].cpu().numpy().view(np.uint8).reshape(-1, 16)
+        got = np.sort(np.frombuffer(rec.tobytes(), dtype=spm.HIT_DTYPE), order=["pattern", "pos"])
+        assert np.array_equal(got, want)
+        assert np.array_equal(h.view(), want) and h.stats().fell_back == 0     # (the accessor completes the scan)
+        h.close()
+    h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
+    h.close()                                                                   # never looked at: completed on destroy
+    # a scan that needs its host: spans give up -> status 1 in the header; view() repeats the scan the ordinary way
+    os.environ["SPM_HIP_FILTER_SPAN_BUDGET"] = "1"
+    try:
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
+        h.copy_fused_device(buf.data_ptr(), cap)
+        ctx.synchronize()
+        assert buf[0, 1].item() == 1
+        got = h.view()
+        st = h.stats()
+    finally:
+        del os.environ["SPM_HIP_FILTER_SPAN_BUDGET"]
+    assert np.array_equal(got, want) and st.fallback_spans > 0
+    h.copy_fused_device(buf.data_ptr(), cap)                                    # completed: final records, status 0
+    ctx.synchronize()
+    assert buf[0].cpu().tolist() == [len(want), 0]
+    # Myers sets ignore the flag (their verification may need a second attempt): same result, completed on return
+    nd = [T[a:a + 100].copy() for a in rng.integers(0, n - 100, 64)]
+    pm = ctx.patterns(spm.ALGO_MYERS, nd, k=2)
+    a = spm.scan(ctx, text, pm, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER).view()
+    b = spm.scan(ctx, text, pm, engine=spm.ENGINE_FILTER).view()
+    assert np.array_equal(a, b) and len(a) >= 64
