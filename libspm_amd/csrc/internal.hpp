@@ -68,6 +68,72 @@ inline bool spm_trace_on()
 }
 
 
+// every knob of a scan, read from the environment in ONE place, once per C-ABI call that scans (defaults: the measured best)
+struct scan_tuning
+{
+    int cand_cap = 0;
+    int brute_cutoff = 1;
+    int verify_wave_threads = 64;
+    int verify_wave_lds_kb = 0;
+    int verify_wave_nb = 1;
+    int verify_wave_min_words = 8;
+    int band_factor = 4;
+    int band = 32;
+    int exact_from_resolve = 1;
+    int exact_skip_dedupe = 1;
+    int dense_debug = 0;
+    int s2_u = 2;
+    int force_masked = 0;
+    int filter_threads = 0;
+    int spans_per_wave = 0;
+    int span = 0;
+    int span_budget = 0;
+    int dyn = -1;
+    int filter_u = 8;
+    int nt = 1;
+    int anchor_u = 4;
+    int seed_check = 1;
+    int flank_check = 1;
+    int pieces_check = 1;
+    int resolve_wgs_per_cu = 5;
+    int resolve_surv_per_wg = 1024;
+    int verify_runs = 1;
+    int verify_runs_min_bands = 65536;
+    static scan_tuning from_env()
+    {
+        scan_tuning T;
+        T.cand_cap = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
+        T.brute_cutoff = env_int("SPM_HIP_BRUTE_CUTOFF", 1);
+        T.verify_wave_threads = env_int("SPM_HIP_VERIFY_WAVE_THREADS", 64);
+        T.verify_wave_lds_kb = env_int("SPM_HIP_VERIFY_WAVE_LDS_KB", 0);
+        T.verify_wave_nb = env_int("SPM_HIP_VERIFY_WAVE_NB", 1);
+        T.verify_wave_min_words = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8);
+        T.band_factor = env_int("SPM_HIP_FILTER_BAND_FACTOR", 4);
+        T.band = env_int("SPM_HIP_FILTER_BAND", 32);
+        T.exact_from_resolve = env_int("SPM_HIP_EXACT_FROM_RESOLVE", 1);
+        T.exact_skip_dedupe = env_int("SPM_HIP_EXACT_SKIP_DEDUPE", 1);
+        T.dense_debug = env_int("SPM_HIP_DENSE_DEBUG", 0);
+        T.s2_u = env_int("SPM_HIP_FILTER_S2_U", 2);
+        T.force_masked = env_int("SPM_HIP_FILTER_FORCE_MASKED", 0);
+        T.filter_threads = env_int("SPM_HIP_FILTER_THREADS", 0);
+        T.spans_per_wave = env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 0);
+        T.span = env_int("SPM_HIP_FILTER_SPAN", 0);
+        T.span_budget = env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0);
+        T.dyn = env_int("SPM_HIP_FILTER_DYN", -1);
+        T.filter_u = env_int("SPM_HIP_FILTER_U", 8);
+        T.nt = env_int("SPM_HIP_FILTER_NT", 1);
+        T.anchor_u = env_int("SPM_HIP_FILTER_ANCHOR_U", 4);
+        T.seed_check = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1);
+        T.flank_check = env_int("SPM_HIP_FLANK_CHECK", 1);
+        T.pieces_check = env_int("SPM_HIP_PIECES_CHECK", 1);
+        T.resolve_wgs_per_cu = env_int("SPM_HIP_RESOLVE_WGS_PER_CU", 5);
+        T.resolve_surv_per_wg = env_int("SPM_HIP_RESOLVE_SURV_PER_WG", 1024);
+        T.verify_runs = env_int("SPM_HIP_VERIFY_RUNS", 1);
+        T.verify_runs_min_bands = env_int("SPM_HIP_VERIFY_RUNS_MIN_BANDS", 65536);
+        return T;
+    }
+};
+
 struct scan_args
 {
     spm_ctx *ctx;
@@ -78,6 +144,7 @@ struct scan_args
     const void *state_in;
     void *state_out;
     spm_hits *hits;
+    scan_tuning tune;                        // the environment's knobs, as this call found them
     const uint64_t *seg_offsets = nullptr; // host; n_segments + 1 entries
     uint64_t n_segments = 0;
     const uint64_t *d_seg_offsets = nullptr; // the same table already resident on the device (journaled-sequence index)

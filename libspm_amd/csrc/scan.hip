@@ -98,6 +98,7 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
 
     scan_args A{ctx, text, begin, end, opts.left_context ? 0 : begin, patterns, opts, state_in, state_out, H.get()};
+    A.tune = scan_tuning::from_env();
     A.seg_offsets = seg_offsets;
     A.n_segments = n_segments;
     A.d_seg_offsets = d_seg_offsets;
@@ -190,7 +191,7 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
             // Start over with more room when the lists were too small for this text (the first attempt counted the
             // demand): survivor buffer full -- spans gave up for that reason, not for their own budget --, or band list /
             // band table / dedupe set full.
-            const bool more_surv = c[1] > H->cand_cap && H->cand_cap < (1ull << 27) && !env_int("SPM_HIP_FILTER_CAND_CAP", 0);
+            const bool more_surv = c[1] > H->cand_cap && H->cand_cap < (1ull << 27) && !A.tune.cand_cap;
             const bool more_bands = c[2] != 0 && c[3] > H->band_cap && H->band_cap < (1ull << 28);
             const bool more_seen = c[2] != 0 && !A.seen_full && !more_bands && c[3] <= H->band_cap;
             if (!more_surv && !more_bands && !more_seen)

@@ -165,7 +165,7 @@ int run_brute(const scan_args &A, uint64_t begin, uint64_t end, uint64_t ctx_beg
     }
     // Ukkonen cut-off kernel for stateless Myers scans (SPM_HIP_BRUTE_CUTOFF=0 selects the full-width kernel)
     const bool cutoff = ps->algo == SPM_ALGO_MYERS && !d_state_in && !d_state_out && ps->d_peq_bot &&
-                        env_int("SPM_HIP_BRUTE_CUTOFF", 1) != 0;
+                        A.tune.brute_cutoff != 0;
     if (cutoff)
         P.peq = ps->d_peq_bot;
     launch_brute(ps, P, dim3(launch_grid), dim3(64 * wpw), lds, ctx->stream, cutoff);

@@ -5,6 +5,8 @@
 
 namespace
 {
+const scan_tuning *g_tune = nullptr; // the knobs of the scan being launched (set by run_filter; launches are host-serial per context)
+scan_tuning g_tune_default;
 template <int NWN>
 void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
@@ -24,7 +26,7 @@ void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max
     // One wave per workgroup: a scan leaves a few thousand long bands, i.e. far fewer busy waves than the GPU has SIMDs,
     // and each is a serial chain ~1500 steps long.  With four-wave workgroups filled in order, the dispatcher packed the
     // busy waves four to a SIMD on a third of the CUs and left the rest idle.
-    const uint32_t threads = (uint32_t)std::max(64, std::min(256, env_int("SPM_HIP_VERIFY_WAVE_THREADS", 64)));
+    const uint32_t threads = (uint32_t)std::max(64, std::min(256, (*(g_tune ? g_tune : &g_tune_default)).verify_wave_threads));
     grid.x *= 256 / threads;
     const uint32_t n_slots = 2 * V.max_k + 1 + V.max_span;
     // text window of one candidate: cold start |P| + k symbols before the first end position, then the end positions
@@ -32,7 +34,7 @@ void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max
     const size_t per_group = ((n_slots * 2 + 15) & ~15u) + V.wave_text;
     size_t lds = (size_t)(threads / 64) * (64 / G) * per_group;
     // (diagnostics: a larger LDS claim per workgroup caps how many of them a CU takes at once)
-    lds = std::max<size_t>(lds, (size_t)std::max(0, std::min(160, env_int("SPM_HIP_VERIFY_WAVE_LDS_KB", 0))) * 1024);
+    lds = std::max<size_t>(lds, (size_t)std::max(0, std::min(160, (*(g_tune ? g_tune : &g_tune_default)).verify_wave_lds_kb)) * 1024);
     hipFuncSetAttribute((const void *)verify_wave_kernel<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_wave_kernel<G, NB>), grid, dim3(threads), lds, s, V, peq_bot);
 }
@@ -44,7 +46,7 @@ void launch_verify_wave(uint32_t n_blocks, const verify_params &V, const uint32_
 {
     // (measured on C5, 2 798 bands of |P| = 1024: one block per lane 0.300 ms, two 0.358 -- a step is a chain of dependent
     // instructions, its latency and not its issue slots set the pace, and the second block lengthens the chain.)
-    const bool two = env_int("SPM_HIP_VERIFY_WAVE_NB", 1) >= 2;
+    const bool two = (*(g_tune ? g_tune : &g_tune_default)).verify_wave_nb >= 2;
     if (n_blocks <= 8)
         launch_verify_wave_g<8, 1>(V, peq_bot, max_m, grid, s);
     else if (n_blocks <= 16)
@@ -105,6 +107,7 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
 
 int run_filter(const scan_args &A)
 {
+    g_tune = &A.tune;
     spm_ctx *ctx = A.ctx;
     const spm_patterns *ps = A.ps;
     spm_hits *H = A.hits;
@@ -128,7 +131,7 @@ int run_filter(const scan_args &A)
     uint64_t surv_cap = std::min(2 * est + (uint64_t)ctx->n_cu * 16 * kChunkMin, kSurvMax);
     if (A.cand_cap_override)
         surv_cap = A.cand_cap_override;
-    const int cc = env_int("SPM_HIP_FILTER_CAND_CAP", 0);
+    const int cc = A.tune.cand_cap;
     if (cc > 0)
         surv_cap = (uint64_t)cc;
     // (+ the first chunk of every wave of resolve_kernel: n_cu x 8 workgroups of 4 waves)
@@ -145,18 +148,18 @@ int run_filter(const scan_args &A)
     // best for |P| = 1024, k = 64; the lane-per-band kernel keeps its end-position slots per thread: narrow bands there).
     // Other sets: 64 diagonals, no overlap -- every band with a seed hit is verified.
     uint32_t nwn = std::max(1u, (ps->max_m + 31) / 32);
-    const int wave_min = env_int("SPM_HIP_VERIFY_WAVE_MIN_WORDS", 8); // 0 = never use the wave-per-band kernel
+    const int wave_min = A.tune.verify_wave_min_words; // 0 = never use the wave-per-band kernel
     // (the wave-per-band kernel keeps the match masks of <= 5 symbols in registers: dna15 sets use the lane-per-band one)
     const bool use_wave = ps->d_peq_bot && wave_min > 0 && nwn >= (uint32_t)wave_min && ps->sigma <= 5;
     const bool overlap = ps->d_surplus != nullptr;
     uint32_t Bw;
     if (overlap) {
-        const uint32_t bw_factor = use_wave ? (uint32_t)std::max(1, env_int("SPM_HIP_FILTER_BAND_FACTOR", 4)) : 1u;
+        const uint32_t bw_factor = use_wave ? (uint32_t)std::max(1, A.tune.band_factor) : 1u;
         Bw = (ps->max_k + 1) * bw_factor;
         if (Bw + ps->max_k > 2047)
             Bw = ps->max_k + 1;
     } else {
-        Bw = (uint32_t)std::max(8, std::min(64, env_int("SPM_HIP_FILTER_BAND", 32))); // (one mask bit per diagonal)
+        Bw = (uint32_t)std::max(8, std::min(64, A.tune.band)); // (one mask bit per diagonal)
     }
     const uint32_t max_span = Bw - 1 + (overlap ? ps->max_k + 1 : 0);
     // dedupe set: one key per reported hit, so twice the hit capacity is room enough; a caller with a huge hit buffer
@@ -180,7 +183,7 @@ int run_filter(const scan_args &A)
     // of the resolve kernel is the whole comparison, so it reports the hits itself -- no band table, no verification launch.
     // (Not for needles that are repeats: their merged index entries skip the per-offset check.)
     bool exact_hits = ps->max_k == 0 && !overlap && ps->filter_max_range == 0 && ps->d_ranks &&
-                      env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) != 0 && env_int("SPM_HIP_EXACT_FROM_RESOLVE", 1) != 0;
+                      A.tune.seed_check != 0 && A.tune.exact_from_resolve != 0;
     if (exact_hits && ps->exact_whole < 0) {
         bool whole = true;
         for (uint32_t p = 0; p < ps->n && whole; ++p)
@@ -206,7 +209,7 @@ int run_filter(const scan_args &A)
     // Exact sets whose hits come from the resolve kernel report every occurrence once by construction (one sampled window,
     // one entry): no dedupe set, no 4 MiB memset in front of a 0.2 ms scan -- unless a span gives up (the brute-force
     // re-scan of that span would report its hits a second time): then the scan runs again with the set.
-    const bool skip_seen = exact_hits && !A.need_seen && env_int("SPM_HIP_EXACT_SKIP_DEDUPE", 1) != 0;
+    const bool skip_seen = exact_hits && !A.need_seen && A.tune.exact_skip_dedupe != 0;
     const_cast<scan_args &>(A).seen_skipped = skip_seen;
     const_cast<scan_args &>(A).exact_used = exact_hits;
     if (!skip_seen)
@@ -248,7 +251,7 @@ int run_filter(const scan_args &A)
         P.pat_cm[i] = F.pat_cm[i];
     }
     P.bucket_shift = F.bucket_shift;
-    P.dense_debug = (uint32_t)env_int("SPM_HIP_DENSE_DEBUG", 0);
+    P.dense_debug = (uint32_t)A.tune.dense_debug;
     P.buckets = reinterpret_cast<const uint4 *>(F.d_buckets);
     if (fi > 0) // each pass draws its spans from a fresh head
         SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count + 4, 0, sizeof(unsigned long long), ctx->stream));
@@ -259,24 +262,24 @@ int run_filter(const scan_args &A)
     // 16-symbol keys (LDS-bound: C4 25.8 vs 29.1 ms; the other stride-1/2 variants need more than 128 VGPRs)
     // stride 2: two chunks per group (16 windows per lane) need < 128 VGPRs, so 16 waves per CU hide the LDS round trips
     // (C5: 0.53 -> 0.46 ms; four chunks per group hold 167 VGPRs at 8 waves)
-    const bool narrow2 = F.stride == 2 && !use_packed && env_int("SPM_HIP_FILTER_S2_U", 2) == 2;
+    const bool narrow2 = F.stride == 2 && !use_packed && A.tune.s2_u == 2;
     const bool wide_ok = use_packed || narrow2 || (F.stride == 1 && F.key_len >= 16 && ps->sigma == 4 &&
-                                                   !env_int("SPM_HIP_FILTER_FORCE_MASKED", 0));
+                                                   !A.tune.force_masked);
     const uint32_t threads = (F.dense || bits) ? 1024u : (uint32_t)std::max(
-        64, std::min(wide_ok ? 1024 : 512, env_int("SPM_HIP_FILTER_THREADS", wide_ok ? 1024 : 512)));
+        64, std::min(wide_ok ? 1024 : 512, (A.tune.filter_threads > 0 ? A.tune.filter_threads : (wide_ok ? 1024 : 512))));
     // + the workgroup's span-dequeue slot (4 words) + one survivor-chunk record per wave (+ dense: one queue per wave)
     const size_t lds = (size_t)F.lds_words * 4 + 16 + 16 * kCandRec * 4 + ((F.dense || bits) ? 16 * sizeof(dense_queue) : 0);
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 2048 / threads));
     const uint32_t grid = ctx->n_cu * wg_per_cu;
     const uint64_t n_waves = (uint64_t)grid * (threads / 64);
     const uint64_t n_chunks = (P.hi - (P.lo & ~1023ull) + 1023) / 1024;
-    uint64_t span = n_chunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 32))) + 1;
+    uint64_t span = n_chunks / (n_waves * (uint64_t)std::max(1, (A.tune.spans_per_wave > 0 ? A.tune.spans_per_wave : 32))) + 1;
     // small texts: at least 64 KiB per dequeue as long as every wave still gets ~4 spans (a 1 GiB text ran 14 % faster
     // with 64-chunk spans than with the 24 the rule above gives: fewer dequeue rounds, each a workgroup barrier)
     if (span < 64)
         span = std::max<uint64_t>(span, std::min<uint64_t>(64, n_chunks / (n_waves * 4) + 1));
     span = std::min<uint64_t>(std::max<uint64_t>(span, 8), 4096);
-    const int fs = env_int("SPM_HIP_FILTER_SPAN", 0);
+    const int fs = A.tune.span;
     if (fs > 0)
         span = (uint64_t)fs;
     span = (span + 7) & ~7ull; // whole groups of chunks
@@ -285,18 +288,18 @@ int run_filter(const scan_args &A)
     // candidates a span may produce before it gives up and is re-scanned by the brute-force kernel: one per 4 symbols
     // costs the verification about what the re-scan would
     {
-        const int sb = env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0);
+        const int sb = A.tune.span_budget;
         P.span_budget = sb > 0 ? (uint32_t)sb : (uint32_t)std::max<uint64_t>(256, span * 1024 / 4);
     }
     // span dequeue: per wave while the dequeue rate stays far below what one atomic word sustains (~88/us, i.e.
     // spans >= 192 KiB at 7 TB/s), per workgroup otherwise (measured: C3 2.52 vs 2.59 ms, C2 0.88 vs 0.20 ms)
-    const int dyn = env_int("SPM_HIP_FILTER_DYN", -1);
+    const int dyn = A.tune.dyn;
     P.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (span >= 192 ? 1u : 2u);
 
-    const int U = env_int("SPM_HIP_FILTER_U", 8) >= 8 ? 8 : 4;
-    const bool NT = env_int("SPM_HIP_FILTER_NT", 1) != 0;
+    const int U = A.tune.filter_u >= 8 ? 8 : 4;
+    const bool NT = A.tune.nt != 0;
     P.hash_variant = F.hash_variant;
-    const bool short_keys = F.key_len < 16 || env_int("SPM_HIP_FILTER_FORCE_MASKED", 0) != 0; // (the env: diagnostics)
+    const bool short_keys = F.key_len < 16 || A.tune.force_masked != 0; // (the env: diagnostics)
 #define LAUNCH_FILTER4(S, UU, NTT, HV, SG, KM)                                                                         \
     do {                                                                                                               \
         hipFuncSetAttribute((const void *)seed_filter_kernel<S, UU, NTT, HV, SG, KM>,                                  \
@@ -388,12 +391,12 @@ int run_filter(const scan_args &A)
         // p-chunks of 4096 symbols: recompute the span geometry in those units
         filter_params Q = P;
         const uint64_t n_pchunks = (Q.hi - (Q.lo & ~4095ull) + 4095) / 4096;
-        uint64_t pspan = n_pchunks / (n_waves * (uint64_t)std::max(1, env_int("SPM_HIP_FILTER_SPANS_PER_WAVE", 8))) + 1;
+        uint64_t pspan = n_pchunks / (n_waves * (uint64_t)std::max(1, (A.tune.spans_per_wave > 0 ? A.tune.spans_per_wave : 8))) + 1;
         pspan = std::min<uint64_t>(std::max<uint64_t>(pspan, 4), 4096);
         pspan = (pspan + 3) & ~3ull;
         Q.span_chunks = (uint32_t)pspan;
         Q.span_unit = 4096;
-        if (env_int("SPM_HIP_FILTER_SPAN_BUDGET", 0) <= 0)
+        if (A.tune.span_budget <= 0)
             Q.span_budget = (uint32_t)std::max<uint64_t>(256, pspan * 4096 / 4);
         Q.dynamic = dyn >= 0 ? (uint32_t)std::min(2, dyn) : (pspan >= 48 ? 1u : 2u);
         const uint4 *shadow = reinterpret_cast<const uint4 *>(A.text->d_packed);
@@ -438,7 +441,7 @@ int run_filter(const scan_args &A)
     default:
         if (F.anchor_cm != 0 && F.hash_variant == 2 && ps->sigma == 4 && !short_keys) {
             // anchored pass: few windows per lane are looked up, so a lane can hold more text
-            const int au = env_int("SPM_HIP_FILTER_ANCHOR_U", 4);
+            const int au = A.tune.anchor_u;
 #define LAUNCH_ANCHORED(UU)                                                                                            \
     do {                                                                                                               \
         hipFuncSetAttribute((const void *)seed_filter_kernel<1, UU, true, 2, 4, false, true>,                          \
@@ -495,11 +498,11 @@ int run_filter(const scan_args &A)
     R.key_len = ps->filter_key_len;
     R.text = A.text->d;
     R.text_alloc = A.text->owned ? A.text->alloc : A.text->n;
-    R.needle_ranks = env_int("SPM_HIP_VERIFY_SEED_CHECK", 1) ? ps->d_ranks : nullptr;
+    R.needle_ranks = A.tune.seed_check ? ps->d_ranks : nullptr;
     R.needle_offsets = ps->d_offsets;
     R.seed_q = ps->d_seed_q;
-    R.flank_check = (ps->sigma == 4 && !overlap && R.needle_ranks && env_int("SPM_HIP_FLANK_CHECK", 1)) ? 1u : 0u;
-    R.pieces_check = env_int("SPM_HIP_PIECES_CHECK", 1) ? R.flank_check : 0u;
+    R.flank_check = (ps->sigma == 4 && !overlap && R.needle_ranks && A.tune.flank_check) ? 1u : 0u;
+    R.pieces_check = A.tune.pieces_check ? R.flank_check : 0u;
     R.m = ps->d_m;
     R.k = ps->d_k;
     R.hay_begin = A.ctx_begin;
@@ -534,9 +537,9 @@ int run_filter(const scan_args &A)
     // (5 workgroups per CU are resident at once -- LDS queues, 84 VGPRs --: a larger grid only adds a second, partly filled
     // round.  A lane takes ~4 survivors in turn: measured on C5, whose survivors are few and cheap, 0.137 -> 0.10 ms;
     // c3r 1.33 -> 1.25 ms with the cap alone.)
-    const uint64_t rmax = (uint64_t)ctx->n_cu * (uint64_t)std::max(1, env_int("SPM_HIP_RESOLVE_WGS_PER_CU", 5));
+    const uint64_t rmax = (uint64_t)ctx->n_cu * (uint64_t)std::max(1, A.tune.resolve_wgs_per_cu);
     // (a short survivor list: one survivor per lane, its latency is the kernel's; a long one: four per lane)
-    const uint64_t per_wg = (surv_expect + 255) / 256 <= rmax ? 256 : (uint64_t)std::max(256, env_int("SPM_HIP_RESOLVE_SURV_PER_WG", 1024));
+    const uint64_t per_wg = (surv_expect + 255) / 256 <= rmax ? 256 : (uint64_t)std::max(256, A.tune.resolve_surv_per_wg);
     const uint32_t rgrid = (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(ctx->n_cu / 2, (surv_expect + per_wg - 1) / per_wg));
     hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, R);
     SPM_HIP_CHECK(ctx, hipGetLastError());
@@ -579,8 +582,8 @@ int run_filter(const scan_args &A)
     V.band_bits = 43 - seg_bits;
     // runs of adjacent bands (filter.hpp, band_runs_kernel): when earlier scans of this set left a long band list -- a
     // repeat-rich text --, sets without surplus seeds, lane-per-band verification
-    const bool runs = !overlap && !exact_hits && !use_wave && Bw <= 32 && !A.need_seen && env_int("SPM_HIP_VERIFY_RUNS", 1) != 0 &&
-                      ps->band_hint >= (uint64_t)std::max(0, env_int("SPM_HIP_VERIFY_RUNS_MIN_BANDS", 65536));
+    const bool runs = !overlap && !exact_hits && !use_wave && Bw <= 32 && !A.need_seen && A.tune.verify_runs != 0 &&
+                      ps->band_hint >= (uint64_t)std::max(0, A.tune.verify_runs_min_bands);
     if (runs) {
         // (heads report most end positions without asking the dedupe set: if a span gives up, the brute-force re-scan
         // could report them again -- the scan then runs once more without runs, as for exact sets without the set)
