@@ -611,7 +611,9 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
     prev = None
     for _ in range(args.steps + 1):
         cur = step() if _ < args.steps else None
-        if prev is not None:            # the step before: its kernels are done or running behind this step's
+        if not fused:                   # this step has synchronised with the host already (its count): read it now, so
+            prev, cur = cur, None       # that its buffers (1 GiB of hit slots on a repeat-rich text) serve the next step
+        if prev is not None:            # fused: the step before -- its kernels are done or running behind this step's
             h, g = prev
             st = h.stats()
             ms_main += st.ms_main
@@ -696,7 +698,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         "all_planted_found": bool(len(found) == n_pat),
         "patterns_create_ms": patterns_create_ms,
         "patterns_create": {"ms_in_the_library": bs.ms_total, "ms_tables": bs.ms_tables, "ms_index": bs.ms_index,
-                            "ms_upload": bs.ms_upload, "host_threads": int(bs.threads), "filter_passes": int(bs.passes),
+                            "ms_upload": bs.ms_upload, "device_bytes": int(bs.bytes_device), "host_threads": int(bs.threads), "filter_passes": int(bs.passes),
                             "dense_pass": bool(bs.dense), "keys": int(bs.keys),
                             "anchor_sixteenths": int(bs.anchor_sixteenths), "stride": int(bs.stride)},
         "first_scan_ms": first_scan_ms,

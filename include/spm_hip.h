@@ -166,13 +166,14 @@ typedef struct spm_build_stats {
     float ms_total;
     float ms_tables;  /* match-mask tables of the bit-vector engines */
     float ms_index;   /* seed index of the filter engine */
-    float ms_upload;  /* device allocations + host-to-device copies */
+    float ms_upload;  /* the device allocation + the host-to-device stream of every table (pinned chunks) */
     uint32_t threads;
     uint32_t passes;            /* passes of the seed filter over the text per scan (0: brute-force engine only) */
     uint32_t dense;             /* 1: the one dense pass (presence bits in LDS + fingerprint buckets in L2) */
     uint32_t anchor_sixteenths; /* sixteenths of all text windows that are looked up, summed over the passes */
     uint64_t keys;              /* indexed windows */
     uint32_t stride, key_len;
+    uint64_t bytes_device;      /* the set's one device allocation (every table, 256-byte aligned) */
 } spm_build_stats;
 int spm_hip_patterns_build_stats(const spm_patterns *p, spm_build_stats *out);
 

@@ -68,6 +68,7 @@ class BuildStats(C.Structure):
         ("keys", C.c_uint64),
         ("stride", C.c_uint32),
         ("key_len", C.c_uint32),
+        ("bytes_device", C.c_uint64),
     ]
 
 

@@ -53,6 +53,10 @@ struct spm_ctx
     ulonglong2 *d_band_tab = nullptr; // {key, value} per slot (filter.hpp: band_value)
     uint64_t band_slots = 0;
     bool band_dirty = false;
+    // pinned staging of needle-set uploads: two halves, so the host fills one while the other travels (patterns.hip)
+    uint8_t *h_stage = nullptr;
+    size_t stage_half = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     unsigned long long *h_counters = nullptr; // pinned: the per-scan counter read-back lands here (a pageable target costs
                                               // an extra staging hop on every scan)
 };

@@ -1295,6 +1295,10 @@ __device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue
     if (act) {
         bool placed = false;
         for (uint32_t tries = 0; tries < 8192 && !placed; ++tries) {
+            // (a table that has overflowed is lost -- the host repeats the scan with a larger one: do not walk a full table
+            // 8192 slots per band, which cost 5 s on a text with 5 % repeats whose first attempt was sized for 1 %)
+            if ((tries & 31u) == 31u && __hip_atomic_load(&R.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                break;
             const unsigned long long o = atomicCAS(&R.band_tab[s2].x, kBandEmpty, bkey);
             if (o == kBandEmpty) {
                 claimed = true;
@@ -1383,6 +1387,10 @@ __device__ __forceinline__ bool seen_insert_raw(unsigned long long *seen, uint32
     // the set holds at most one key per reportable hit at load <= 1/2; a probe sequence this long means more hits than
     // it was sized for: flag it, the host starts over with a larger one
     for (uint32_t tries = 0; tries < 64; ++tries) {
+        // (a set that has overflowed once is lost -- the host repeats the scan: do not grind through 64 compare-and-swaps
+        // per hit of a full table, 5 s for the 46 M hits of a text with 5 % repeats)
+        if (tries == 4 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            return false;
         const unsigned long long old = atomicCAS(&seen[slot], ~0ull, key);
         if (old == ~0ull)
             return true;
@@ -1564,6 +1572,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride; // wave-uniform trip count: the queue and the appends are wave-collective
     for (uint64_t r = 0; r < rounds; ++r) {
+        // a list or table of this attempt has overflowed: its results are void (the host starts over), stop feeding it
+        if ((r & 7u) == 7u &&
+            __builtin_amdgcn_readfirstlane((uint32_t)(__hip_atomic_load(&R.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
+            break;
         const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
         bool probing = false;
         uint32_t key = 0;

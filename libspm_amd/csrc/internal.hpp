@@ -35,6 +35,7 @@ struct spm_patterns : spm_hip::seed_index // (the seed index: passes, entries, s
     uint32_t NW = 1;   // 32-bit words per needle in the brute kernels (power of two)
     bool is_myers() const { return algo == SPM_ALGO_MYERS || algo == SPM_ALGO_MYERS_PREFIX; }
     // device
+    void *d_arena = nullptr;   // the set's one device allocation: every d_* table below points into it (patterns.hip)
     uint32_t *d_peq = nullptr; // [group][sigma+1][NW][64], needles top-aligned
     uint32_t *d_peq_bot = nullptr; // Myers only: same shape, needles bottom-aligned (cut-off kernel)
     uint32_t *d_peq_verify = nullptr; // exact matchers: Myers-style match masks (top-aligned) for the verify kernel;

@@ -4,6 +4,85 @@
 #include "internal.hpp"
 #include "tables_build.hpp"
 
+// Every table of a needle set lives in ONE device allocation and travels in one stream of pinned chunks: the sources are laid
+// end to end (256-byte aligned), the context's two staging halves are filled by turns (a thread team copies when the set is
+// large) and each half goes up with one asynchronous copy while the other is being filled.  Twenty hipMalloc + pageable
+// hipMemcpy calls cost 12 ms for 1024 needles and 55 ms for 100 000; this costs what the bytes cost.
+namespace
+{
+struct needle_upload
+{
+    struct item
+    {
+        void **dst;
+        const void *src;
+        size_t bytes, off;
+    };
+    std::vector<item> items;
+    size_t total = 0;
+    size_t add(void **dst, const void *src, size_t bytes, size_t zero_tail = 0)
+    {
+        items.push_back(item{dst, src, bytes, total});
+        total += (std::max<size_t>(bytes + zero_tail, 16) + 255) & ~(size_t)255;
+        return items.size() - 1;
+    }
+    // the allocation; every *dst points into it afterwards
+    hipError_t place(void **arena)
+    {
+        hipError_t e = hipMalloc(arena, std::max<size_t>(total, 256));
+        if (e != hipSuccess)
+            return e;
+        for (item &it : items)
+            *it.dst = static_cast<uint8_t *>(*arena) + it.off;
+        return hipSuccess;
+    }
+    // bytes [lo, hi) of the laid-out image into `out` (gaps and tails are zero)
+    void fill(uint8_t *out, size_t lo, size_t hi) const
+    {
+        memset(out, 0, hi - lo);
+        size_t i = std::upper_bound(items.begin(), items.end(), lo, [](size_t v, const item &it) { return v < it.off; }) - items.begin();
+        i = i ? i - 1 : 0;
+        for (; i < items.size() && items[i].off < hi; ++i) {
+            const item &it = items[i];
+            const size_t a = std::max(lo, it.off), b = std::min(hi, it.off + it.bytes);
+            if (a < b && it.src)
+                memcpy(out + (a - lo), static_cast<const uint8_t *>(it.src) + (a - it.off), b - a);
+        }
+    }
+    hipError_t stream(spm_ctx *ctx, void *arena, unsigned n_threads) const
+    {
+        const size_t half = ctx->stage_half;
+        std::unique_ptr<thread_team> team;
+        if (total > 4 * half && n_threads > 1)
+            team.reset(new thread_team(std::min(n_threads, 8u)));
+        hipError_t e = hipSuccess;
+        unsigned c = 0;
+        for (size_t lo = 0; lo < total && e == hipSuccess; lo += half, ++c) {
+            const size_t hi = std::min(total, lo + half);
+            uint8_t *h = ctx->h_stage + (c & 1) * half;
+            if (c >= 2)
+                e = hipEventSynchronize(ctx->stage_ev[c & 1]); // the copy that last read this half
+            if (e != hipSuccess)
+                break;
+            if (team)
+                team->run((hi - lo + 65535) / 65536, [&](size_t b0, size_t b1, unsigned) {
+                    const size_t a = lo + b0 * 65536, b = std::min(hi, lo + b1 * 65536);
+                    if (a < b)
+                        fill(h + (a - lo), a, b);
+                });
+            else
+                fill(h, lo, hi);
+            e = hipMemcpyAsync(static_cast<uint8_t *>(arena) + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(ctx->stage_ev[c & 1], ctx->stream);
+        }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream); // the staging halves are free again; the caller's vectors may go
+        return e;
+    }
+};
+} // namespace
+
 extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ranks_concat, const uint32_t *offsets,
                                        uint32_t n_patterns, const uint16_t *k, uint32_t sigma, spm_patterns **out)
 {
@@ -54,21 +133,22 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
     nv.m = ps->m.data();
     nv.k = ps->k.data();
     nv.max_k = ps->max_k;
+    needle_upload up; // every table of the set: one device allocation, one stream of pinned chunks at the end
     auto upload = [&](auto **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(bytes, 16));
-        if (e == hipSuccess && bytes)
-            e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        return e;
+        up.add(reinterpret_cast<void **>(dst), src, bytes);
+        return hipSuccess;
     };
     double ms_upload = 0;
+    long pass_tab_item = -1;
+    std::vector<uint32_t> pk, pk_off;
+    std::vector<uint8_t> surplus;
     auto t0 = clk::now();
 
     // ---- match-mask tables: [group][row][word][lane], needles top-aligned (see brute.hpp) ----
+    brute_tables bt;
     {
-        brute_tables bt;
         build_brute_tables(nv, ps->n_groups, NW, sigma <= 5 || sigma == 15, tune.n_threads(), bt);
         ps->build.ms_tables = ms_since(t0);
-        const auto tu = clk::now();
         SPM_HIP_CHECK(ctx, upload(&ps->d_peq, bt.peq.data(), bt.peq.size() * sizeof(uint32_t)));
         if (!bt.verify.empty()) // the filter engine verifies exact matchers with the Myers recurrence at k = 0
             SPM_HIP_CHECK(ctx, upload(&ps->d_peq_verify, bt.verify.data(), bt.verify.size() * sizeof(uint32_t)));
@@ -78,7 +158,6 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
             SPM_HIP_CHECK(ctx, upload(&ps->d_hp0, bt.hp0.data(), bt.hp0.size() * sizeof(uint32_t)));
         SPM_HIP_CHECK(ctx, upload(&ps->d_m, ps->m.data(), ps->m.size() * sizeof(int32_t)));
         SPM_HIP_CHECK(ctx, upload(&ps->d_k, ps->k.data(), ps->k.size() * sizeof(int32_t)));
-        ms_upload += ms_since(tu);
     }
 
     // ---- filter engine tables (verification reads the brute table) ----
@@ -88,9 +167,7 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
         if (rc != SPM_OK)
             return rc;
         ps->build.ms_index = ms_since(ti);
-        const auto tu = clk::now();
         if (!ps->fidx.empty()) {
-            std::vector<pass_entry> pt;
             for (filter_index &F : ps->fidx) {
                 SPM_HIP_CHECK(ctx, upload(&F.d_bitmap, F.h_image.data(), F.h_image.size() * sizeof(uint32_t)));
                 SPM_HIP_CHECK(ctx, upload(&F.d_ht, F.h_ht.data(), F.h_ht.size() * sizeof(u32x4)));
@@ -99,22 +176,13 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
                 ps->build.keys += F.n_keys;
                 for (uint32_t d = 0; d < 16; ++d)
                     ps->build.anchor_sixteenths += (F.dimer_set >> d) & 1u;
-                F.h_image = std::vector<uint32_t>();
-                F.h_ht = std::vector<u32x4>();
-                F.h_buckets = std::vector<uint16_t>();
-                pt.push_back(pass_entry{reinterpret_cast<const uint4 *>(F.d_ht), F.ht_mask, 0});
             }
-            SPM_HIP_CHECK(ctx, upload(&ps->d_pass_tab, pt.data(), pt.size() * sizeof(pass_entry)));
+            pass_tab_item = (long)up.add(reinterpret_cast<void **>(&ps->d_pass_tab), nullptr, ps->fidx.size() * sizeof(pass_entry));
             SPM_HIP_CHECK(ctx, upload(&ps->d_entries, ps->h_entries.data(), ps->h_entries.size() * sizeof(u32x4)));
-            ps->h_entries = std::vector<u32x4>();
-            const size_t nr = ps->ranks.size() + 64; // padded: resolve_kernel reads whole dwords around a seed
-            SPM_HIP_CHECK(ctx, hipMalloc(&ps->d_ranks, nr));
-            SPM_HIP_CHECK(ctx, hipMemset(ps->d_ranks, 0, nr));
-            if (!ps->ranks.empty())
-                SPM_HIP_CHECK(ctx, hipMemcpy(ps->d_ranks, ps->ranks.data(), ps->ranks.size(), hipMemcpyHostToDevice));
+            // (64 zero bytes behind the symbols: resolve_kernel reads whole dwords around a seed)
+            up.add(reinterpret_cast<void **>(&ps->d_ranks), ps->ranks.data(), ps->ranks.size(), 64);
             SPM_HIP_CHECK(ctx, upload(&ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t)));
             if (ps->sigma == 4) { // the same symbols 2 bits each, 16 per word, every needle from a word of its own
-                std::vector<uint32_t> pk, pk_off;
                 pack_needles(nv, pk, pk_off);
                 SPM_HIP_CHECK(ctx, upload(&ps->d_needle_pk, pk.data(), pk.size() * sizeof(uint32_t)));
                 SPM_HIP_CHECK(ctx, upload(&ps->d_pk_offsets, pk_off.data(), pk_off.size() * sizeof(uint32_t)));
@@ -122,12 +190,33 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
             SPM_HIP_CHECK(ctx, upload(&ps->d_seed_q, ps->seed_q.data(), ps->seed_q.size() * sizeof(uint16_t)));
         }
         if (!ps->fidx.empty() && ps->max_k >= kMergeMinK && ps->max_k <= 1000) {
-            std::vector<uint8_t> surplus(ps->m.size(), 1);
+            surplus.assign(ps->m.size(), 1);
             for (uint32_t p = 0; p < ps->n; ++p)
                 surplus[p] = (uint8_t)(ps->seed_n[p] - (uint32_t)ps->k[p]);
             SPM_HIP_CHECK(ctx, upload(&ps->d_surplus, surplus.data(), surplus.size()));
         }
-        ms_upload += ms_since(tu);
+    }
+    {
+        const auto tu = clk::now();
+        SPM_HIP_CHECK(ctx, up.place(&ps->d_arena));
+        const double ms_place = ms_since(tu);
+        std::vector<pass_entry> pt;
+        for (filter_index &F : ps->fidx)
+            pt.push_back(pass_entry{reinterpret_cast<const uint4 *>(F.d_ht), F.ht_mask, 0});
+        if (pass_tab_item >= 0)
+            up.items[(size_t)pass_tab_item].src = pt.data();
+        SPM_HIP_CHECK(ctx, up.stream(ctx, ps->d_arena, tune.n_threads()));
+        for (filter_index &F : ps->fidx) {
+            F.h_image = std::vector<uint32_t>();
+            F.h_ht = std::vector<u32x4>();
+            F.h_buckets = std::vector<uint16_t>();
+        }
+        ps->h_entries = std::vector<u32x4>();
+        ps->build.bytes_device = up.total;
+        ms_upload = ms_since(tu);
+        if (spm_trace_on())
+            fprintf(stderr, "[spm_hip] patterns_create: one allocation of %.2f MiB in %.2f ms, streamed up in %.2f ms\n",
+                    up.total / 1048576.0, ms_place, ms_upload - ms_place);
     }
     ps->build.ms_upload = (float)ms_upload;
     ps->build.ms_total = ms_since(t_begin);
@@ -157,25 +246,7 @@ extern "C" void spm_hip_patterns_destroy(spm_patterns *p)
 {
     if (!p)
         return;
-    hipFree(p->d_peq);
-    hipFree(p->d_peq_bot);
-    hipFree(p->d_peq_verify);
-    hipFree(p->d_hp0);
-    hipFree(p->d_m);
-    hipFree(p->d_k);
-    hipFree(p->d_surplus);
-    hipFree(p->d_ranks);
-    hipFree(p->d_offsets);
-    hipFree(p->d_needle_pk);
-    hipFree(p->d_pk_offsets);
-    hipFree(p->d_pass_tab);
-    hipFree(p->d_entries);
-    hipFree(p->d_seed_q);
-    for (filter_index &F : p->fidx) {
-        hipFree(F.d_bitmap);
-        hipFree(F.d_ht);
-        hipFree(F.d_buckets);
-    }
+    hipFree(p->d_arena); // (every d_* table of the set points into it)
     delete p;
 }
 

@@ -8,14 +8,26 @@ int ensure_scratch(spm_ctx *ctx, size_t bytes)
 {
     if (ctx->scratch_bytes >= bytes)
         return SPM_OK;
+    const auto t0 = clk::now();
     if (ctx->d_scratch) {
         SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         SPM_HIP_CHECK(ctx, hipFree(ctx->d_scratch));
         ctx->d_scratch = nullptr;
         ctx->scratch_bytes = 0;
     }
-    SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, bytes));
-    ctx->scratch_bytes = bytes;
+    // what a scan needs follows what earlier scans counted, and those counts wobble by a few per cent from run to run (slots
+    // are drawn in chunks): a quarter of headroom, so that a text with millions of candidates does not pay for a new multi-GB
+    // allocation (hundreds of ms) every few scans
+    size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&ctx->d_scratch, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, want));
+    }
+    ctx->scratch_bytes = want;
+    if (spm_trace_on())
+        fprintf(stderr, "[spm_hip] scratch (survivor / band lists, dedupe set) grows to %.1f MiB: %.2f ms\n", want / 1048576.0, ms_since(t0));
     return SPM_OK;
 }
 
@@ -88,7 +100,10 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
                 break;
             }
         if (!reused) {
+            const auto ta = clk::now();
             SPM_HIP_CHECK(ctx, hipMalloc(&H->d_hits, std::max<uint64_t>(H->cap, 1) * sizeof(spm_hit)));
+            if (spm_trace_on())
+                fprintf(stderr, "[spm_hip] a new hit buffer (%llu records): %.2f ms\n", (unsigned long long)H->cap, ms_since(ta));
             SPM_HIP_CHECK(ctx, hipMalloc(&H->d_count, 16 * sizeof(unsigned long long)));
             for (int i = 0; i < 4; ++i)
                 SPM_HIP_CHECK(ctx, hipEventCreate(&H->ev[i]));
@@ -196,12 +211,18 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
             const bool more_seen = c[2] != 0 && !A.seen_full && !more_bands && c[3] <= H->band_cap;
             if (!more_surv && !more_bands && !more_seen)
                 break;
+            if (spm_trace_on())
+                fprintf(stderr, "[spm_hip] scan attempt %d starts over:%s%s%s (survivor slots drawn %llu of %llu, band slots %llu of %llu, "
+                                "overflow flags %llu, spans that gave up %llu)\n",
+                        attempt, more_surv ? " survivor list too small" : "", more_bands ? " band list too small" : "",
+                        more_seen ? " dedupe set too small" : "", c[1], (unsigned long long)H->cand_cap, c[3],
+                        (unsigned long long)H->band_cap, c[2], c[6]);
             if (more_surv)
                 A.cand_cap_override = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(c[1] + c[1] / 8 + 4096, 4 * H->cand_cap));
             if (more_bands)
                 A.band_scale = std::max<uint64_t>(1, A.band_scale) * std::max<uint64_t>(2, (c[3] + H->band_cap - 1) / H->band_cap + 1);
-            if (more_seen)
-                A.seen_full = true;
+            if (more_seen || ((more_surv || more_bands) && c[0] > ((uint64_t)A.seen_mask + 1) / 8))
+                A.seen_full = true; // (an attempt cut short by its lists that nearly filled the set: the full one will not fit)
             SPM_HIP_CHECK(ctx, hipMemsetAsync(H->d_count, 0, 16 * sizeof(unsigned long long), ctx->stream));
             H->stats.main_launches = 0;
         }

@@ -91,6 +91,7 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
     if (ctx->band_slots >= slots && !ctx->band_dirty)
         return SPM_OK;
     if (ctx->band_slots < slots) {
+        const auto t0 = clk::now();
         if (ctx->d_band_tab) {
             SPM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             hipFree(ctx->d_band_tab);
@@ -99,6 +100,8 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
         }
         SPM_HIP_CHECK(ctx, hipMalloc(&ctx->d_band_tab, slots * sizeof(ulonglong2)));
         ctx->band_slots = slots;
+        if (spm_trace_on())
+            fprintf(stderr, "[spm_hip] band table grows to %.1f MiB: %.2f ms\n", slots * sizeof(ulonglong2) / 1048576.0, ms_since(t0));
     }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_tab, 0xFF, ctx->band_slots * sizeof(ulonglong2), ctx->stream)); // all free
     ctx->band_dirty = false;

@@ -39,12 +39,26 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
         ctx->own_stream = true;
     }
     SPM_HIP_CHECK(none, hipHostMalloc(&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+    // needle sets go up through pinned memory in one stream of chunks (a pageable hipMemcpy per table costs a staging hop
+    // and a synchronisation each: 12 of the 16 ms of creating 1024 needles)
+    ctx->stage_half = (size_t)8 << 20;
+    SPM_HIP_CHECK(none, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), 2 * ctx->stage_half, hipHostMallocDefault));
+    for (int e = 0; e < 2; ++e)
+        SPM_HIP_CHECK(none, hipEventCreateWithFlags(&ctx->stage_ev[e], hipEventDisableTiming));
+    // the first host-to-device copy of a process sets up the copy engine's queue (7 of the 8 ms of uploading the 2 MB of a
+    // 1024-needle set): done here, with the first device-to-host one
+    if (hipMalloc(&ctx->d_scratch, (size_t)64 << 20) == hipSuccess) {
+        ctx->scratch_bytes = (size_t)64 << 20;
+        memset(ctx->h_stage, 0, ctx->stage_half); // (a copy of the size the uploads use: small ones take another path)
+        (void)hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, ctx->stage_half, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipEventRecord(ctx->stage_ev[0], ctx->stream);
+        (void)hipMemcpyAsync(ctx->h_counters, ctx->d_scratch, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    } else {
+        ctx->d_scratch = nullptr;
+    }
     // what the first scan would otherwise allocate in front of its kernels (~0.1 ms per hipMalloc / event): a first piece of
     // scratch (survivor / band lists of a text up to ~2 GiB) and one recycled hit block of the default capacity
-    if (hipMalloc(&ctx->d_scratch, (size_t)64 << 20) == hipSuccess)
-        ctx->scratch_bytes = (size_t)64 << 20;
-    else
-        ctx->d_scratch = nullptr;
     {
         hits_block b;
         b.cap = 1ull << 20;
@@ -93,6 +107,11 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
         hipFree(b.first);
     if (ctx->h_counters)
         hipHostFree(ctx->h_counters);
+    if (ctx->h_stage)
+        hipHostFree(ctx->h_stage);
+    for (int e = 0; e < 2; ++e)
+        if (ctx->stage_ev[e])
+            hipEventDestroy(ctx->stage_ev[e]);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_scratch);
