@@ -259,7 +259,8 @@ def run_c5(args, S, sdist, torch, dist, rank, world, dev, ctx):
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": c5_traffic(int(st.context_symbols), engine_used),
-            "kernel": "seed_filter_kernel" if engine_used == "filter" else "myers_cutoff_kernel",
+            # (stride 2 with presence bits as level 1 runs as an instance of the dense kernel: filter.hpp, dense_group S = 2)
+            "kernel": "seed_filter_dense_kernel<4, 1, 2, true>" if engine_used == "filter" else "myers_cutoff_kernel",
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": int(st.context_symbols),
             "note": "algorithmic bytes = the deduplicated context buffer this GPU streams per search (1 byte per "

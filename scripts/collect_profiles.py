@@ -53,7 +53,7 @@ for w in ("c3", "c4", "c5", "c3r"):
 # HBM traffic of every config: FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE, KB units, separate passes.
 #   per launch of the dominant (streaming) kernel  -> roofline.traffic, comparable with roofline.achieved
 #   per step, all kernels of one scan              -> what resolve / verification / hit copies add
-MAIN = {"c3": "seed_filter_kernel", "c2": "seed_filter_kernel", "c4": "seed_filter_dense_kernel", "c5": "seed_filter_kernel",
+MAIN = {"c3": "seed_filter_kernel", "c2": "seed_filter_kernel", "c4": "seed_filter_dense_kernel", "c5": "seed_filter_dense_kernel",
         "c3r": "seed_filter_kernel", "reads100": "seed_filter_dense_kernel"}
 SETUP = ("synth_", "jst_dedupe", "jst_emit", "jst_chunk", "jst_delta", "jst_start", "jst_alo", "jst_widen", "vectorized_elementwise",
          "text_validate", "text_pack", "rocprim", "hipcub")
@@ -120,12 +120,12 @@ with open(f"{dst}/c3r_sweep.md", "w") as g:
             "`bench.py --workload c3r --repeat-frac F --repeat-needle-every E` (libspm_amd/csrc/synth.hpp says how the text "
             "and the needles are made); hits == the brute-force engine's on a 64 MiB slice in every row.\n\n"
             "| repeat fraction | needles cut across a stretch on purpose | Gbases/s | ms/step | filter kernel ms | survivors' "
-            "candidates | bands verified | hits | spans re-scanned |\n|---|---|---|---|---|---|---|---|---|\n")
+            "candidates | bands verified | hits | spans re-scanned | first scan ms |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for frac, forced, r in sorted(rows, key=lambda x: (x[0], x[1])):
         g.write(f"| {frac:g} | {forced} of {r['config']['needles']} | {r['value']:.0f} | {r['ms_per_step']:.2f} | "
                 f"{r['roofline']['kernel_ms']:.2f} | {r['candidates']} | {r['bands_verified']} | {r['hits']} | "
-                f"{r['fallback_spans']} |\n")
-for f in ("hbm_read_probe.log", "l2_gather_probe.log"):
+                f"{r['fallback_spans']} | {r['first_scan_ms']:.1f} |\n")
+for f in ("hbm_read_probe.log", "l2_gather_probe.log", "c3_gpus2_gloo.json", "c4_gpus2_gloo.json", "c5_gpus2_gloo.json", "progress.log"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{f}")
 print(open(f"{dst}/c3r_sweep.md").read())
