@@ -82,10 +82,14 @@ for w, main in MAIN.items():
             per = None
             break
         # the launches of full scans only (the last ones: warm-up scans of a fresh needle set may repeat a launch)
-        mv = [float(r["Counter_Value"]) for r in mains][-2:]
+        # (c3r's run ends with a 64 MiB parity slice through the same kernel: only launches of the full text count)
+        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in mains]
+        full = [r for r, d in zip(mains, dur) if d >= 0.5 * max(dur)]
+        mv = [float(r["Counter_Value"]) for r in full][-2:]
         per[name] = sum(mv) / len(mv)
         # every kernel of one step: everything between the last two launches of the main kernel (exclusive of set-up kernels)
-        idx = [i for i, r in enumerate(rows) if main in r["Kernel_Name"]]
+        idx = [i for i, r in enumerate(rows) if main in r["Kernel_Name"] and
+               int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.5 * max(dur)]
         lo, hi = idx[-2], idx[-1]
         per[name + "_step"] = sum(float(r["Counter_Value"]) for r in rows[lo:hi] if not any(x in r["Kernel_Name"] for x in SETUP))
     if not per:
