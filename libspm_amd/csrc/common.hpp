@@ -94,6 +94,9 @@ struct spm_hits
     // deferred completion (SPM_SCAN_DEFER): the counters are on their way to h_c behind ev_done; what the scan was, in case
     // it has to be repeated
     bool pending = false;
+    bool c_on_the_way = false;  // ... the copy of the counters into h_c has been enqueued (by the scan, or by the device-side
+                                // fused copy, whose kernel writes them itself: one launch less in a C2 step)
+    bool d_count_cleared = false; // the fused-copy kernel consumed the device counters and cleared them for the next scan
     unsigned long long *h_c = nullptr;
     hipEvent_t ev_done = nullptr;
     const spm_text *d_text = nullptr;

@@ -116,9 +116,13 @@ extern "C" int spm_hip_hits_copy_fused(spm_hits *h, void *device_dst, uint64_t c
 }
 
 // [count | status | records] without the host: the counters are read on the device.  status != 0: a list overflowed or
-// spans gave up -- the host has to complete the scan (scan.hip: spm_complete_deferred).
+// spans gave up -- the host has to complete the scan (scan.hip: spm_complete_deferred).  The kernel also delivers the
+// counters to the result's pinned block (`host_c`, device-visible host memory) and, once every workgroup has read them
+// (a ticket in the spare slot 15), clears them for the scan that will reuse the block: a deferred C2 step is three
+// launches -- streaming, resolve, this -- instead of five.
 __global__ __launch_bounds__(256) void hits_fused_copy_device_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src,
-                                                                       const unsigned long long *__restrict__ counters,
+                                                                       unsigned long long *__restrict__ counters,
+                                                                       unsigned long long *__restrict__ host_c,
                                                                        unsigned long long cap, unsigned long long hit_cap,
                                                                        unsigned long long cand_cap)
 {
@@ -128,14 +132,34 @@ __global__ __launch_bounds__(256) void hits_fused_copy_device_kernel(uint4 *__re
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0)
         dst[0] = make_uint4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)status, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < 13 && host_c)
+        host_c[threadIdx.x] = counters[threadIdx.x];
     for (uint64_t r = i; r < n_copy; r += (uint64_t)gridDim.x * blockDim.x)
         dst[1 + r] = src[r];
+    if (host_c) {
+        __syncthreads(); // (every thread of this workgroup has read what it needs of the counters)
+        __shared__ unsigned int last;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(&counters[15], 1ull) == (unsigned long long)gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last && threadIdx.x < 16)
+            counters[threadIdx.x] = 0;
+    }
 }
 
 extern "C" int spm_hip_hits_copy_fused_device(spm_hits *h, void *device_dst, uint64_t cap)
 {
     if (!h || !device_dst || ((uintptr_t)device_dst & 15))
         return SPM_E_INVALID;
+    if (h->pending && h->c_on_the_way) {
+        // a second device-side copy of the same deferred result: the counters have gone to the host (and the device's
+        // copy may be cleared): complete the scan there first
+        const int rc = hits_count(h);
+        if (rc != SPM_OK && rc != SPM_E_OVERFLOW)
+            return rc;
+    }
     if (!h->pending && h->counted) {
         // the host has completed this scan (its fallbacks included; the device counters may still show what it handled):
         // the count it knows, status 0
@@ -147,10 +171,16 @@ extern "C" int spm_hip_hits_copy_fused_device(spm_hits *h, void *device_dst, uin
         return SPM_OK;
     }
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((std::min<uint64_t>(cap, h->cap) + 255) / 256, (uint64_t)h->ctx->n_cu));
+    unsigned long long *host_c = h->pending ? h->h_c : nullptr; // (a deferred scan: its counters travel with this launch)
     hipLaunchKernelGGL(hits_fused_copy_device_kernel, dim3(grid), dim3(256), 0, h->ctx->stream, static_cast<uint4 *>(device_dst),
-                       reinterpret_cast<const uint4 *>(h->d_hits), h->d_count, (unsigned long long)cap,
+                       reinterpret_cast<const uint4 *>(h->d_hits), h->d_count, host_c, (unsigned long long)cap,
                        (unsigned long long)h->cap, (unsigned long long)(h->cand_cap ? h->cand_cap : ~0ull));
     SPM_HIP_CHECK(h->ctx, hipGetLastError());
+    if (host_c) {
+        SPM_HIP_CHECK(h->ctx, hipEventRecord(h->ev_done, h->ctx->stream));
+        h->c_on_the_way = true;
+        h->d_count_cleared = true;
+    }
     return SPM_OK;
 }
 
@@ -207,7 +237,8 @@ extern "C" void spm_hip_hits_destroy(spm_hits *h)
         b.h_c = h->h_c;
         b.ev_done = h->ev_done;
         // the next scan's counters: cleared now, behind this scan's last read of them (stream order), not in front of that scan
-        b.zeroed = hipMemsetAsync(b.d_count, 0, 16 * sizeof(unsigned long long), h->ctx->stream) == hipSuccess;
+        // (a deferred scan whose counters went out through the device-side fused copy has cleared them there)
+        b.zeroed = h->d_count_cleared || hipMemsetAsync(b.d_count, 0, 16 * sizeof(unsigned long long), h->ctx->stream) == hipSuccess;
         h->ctx->pool.push_back(b); // stream order makes reuse by the next scan safe
     } else {
         if (h->ctx)

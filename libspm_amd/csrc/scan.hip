@@ -180,9 +180,11 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
                     SPM_HIP_CHECK(ctx, hipHostMalloc(&H->h_c, 16 * sizeof(unsigned long long), hipHostMallocDefault));
                 if (!H->ev_done)
                     SPM_HIP_CHECK(ctx, hipEventCreateWithFlags(&H->ev_done, hipEventDisableTiming));
-                SPM_HIP_CHECK(ctx, hipMemcpyAsync(H->h_c, H->d_count, 13 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-                SPM_HIP_CHECK(ctx, hipEventRecord(H->ev_done, ctx->stream));
+                // (the copy itself is enqueued by whoever asks first: spm_hip_hits_copy_fused_device lets its kernel write the
+                // counters to the pinned block -- no launch of its own --, anything else enqueues it in spm_complete_deferred)
                 H->pending = true;
+                H->c_on_the_way = false;
+                H->d_count_cleared = false;
                 H->d_text = text;
                 H->d_patterns = patterns;
                 H->d_begin = begin;
@@ -477,6 +479,11 @@ int spm_complete_deferred(spm_hits *h)
         return SPM_OK;
     spm_ctx *ctx = h->ctx;
     h->pending = false;
+    if (!h->c_on_the_way) {
+        SPM_HIP_CHECK(ctx, hipMemcpyAsync(h->h_c, h->d_count, 13 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        SPM_HIP_CHECK(ctx, hipEventRecord(h->ev_done, ctx->stream));
+        h->c_on_the_way = true;
+    }
     SPM_HIP_CHECK(ctx, hipEventSynchronize(h->ev_done));
     const unsigned long long *c = h->h_c;
     h->stats.n_candidates = c[5];
@@ -514,6 +521,8 @@ int spm_complete_deferred(spm_hits *h)
     h->timed = again->timed;
     h->sorted_host = false;
     h->host.clear();
+    again->d_count_cleared = h->d_count_cleared; // (the flags follow the buffers they describe)
+    h->d_count_cleared = false;
     spm_hip_hits_destroy(again);
     return SPM_OK;
 }

@@ -238,6 +238,25 @@ def test_deferred_completion_of_exact_scans(spm, ctx):
         h.close()
     h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
     h.close()                                                                   # never looked at: completed on destroy
+    # the fused-copy kernel delivers the counters to the host block and clears the device's for the scan that reuses the
+    # buffers: steps back to back without a host access in between (what bench.py's C2 loop does), a second device-side
+    # copy of one result, and an ordinary (Myers) scan on the recycled block
+    buf2 = torch.zeros((cap + 1, 2), dtype=torch.int64, device="cuda")
+    prev = None
+    for _ in range(4):
+        h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
+        h.copy_fused_device(buf.data_ptr(), cap)
+        if prev is not None:
+            assert prev.stats().n_hits == len(want)
+            prev.close()
+        prev = h
+    prev.copy_fused_device(buf2.data_ptr(), cap)                                # again: completed on the host first
+    ctx.synchronize()
+    assert buf[0].cpu().tolist() == [len(want), 0] and torch.equal(buf[:1 + len(want)], buf2[:1 + len(want)])
+    prev.close()
+    nd0 = [T[a:a + 64].copy() for a in rng.integers(0, n - 64, 32)]
+    pm0 = ctx.patterns(spm.ALGO_MYERS, nd0, k=1)
+    assert np.array_equal(spm.scan(ctx, text, pm0, engine=spm.ENGINE_FILTER).view(), spm.scan(ctx, text, pm0, engine=spm.ENGINE_BRUTE).view())
     # a scan that needs its host: spans give up -> status 1 in the header; view() repeats the scan the ordinary way
     os.environ["SPM_HIP_FILTER_SPAN_BUDGET"] = "1"
     try:
