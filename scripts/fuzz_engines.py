@@ -78,6 +78,48 @@ def make_case(rng, spm):
     return dict(n=n, sigma=sigma, T=T, algo=algo, needles=needles, ks=np.asarray(ks, dtype=np.uint16), env=env)
 
 
+def _sorted(h):
+    return h[np.lexsort((h["score"], h["pos"], h["pattern"]))]
+
+
+def check_chunks(spm, ctx, rng, c, text, ps, seed):
+    """Restorable scanning: the text in 2..5 chunks, the state carried from chunk to chunk (capture / restore); hits and
+    final state of the filter route == the brute-force route's == one whole scan."""
+    n = c["n"]
+    cuts = sorted({0, n, *[int(x) for x in rng.integers(1, n, int(rng.integers(1, 5)))]})
+    res = {}
+    for engine in (spm.ENGINE_AUTO, spm.ENGINE_BRUTE):
+        st = ps.initial_state()
+        hits = []
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            h, st = spm.scan(ctx, text, ps, b, e, engine=engine, state_in=st, want_state=True, max_hits=1 << 24)
+            hits.append(h.view().copy())
+            h.close()
+        res[engine] = (_sorted(np.concatenate(hits)), st.copy())
+    whole = _sorted(spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE, max_hits=1 << 24).view().copy())
+    ok = (np.array_equal(res[spm.ENGINE_AUTO][0], res[spm.ENGINE_BRUTE][0]) and
+          np.array_equal(res[spm.ENGINE_AUTO][1], res[spm.ENGINE_BRUTE][1]) and np.array_equal(res[spm.ENGINE_BRUTE][0], whole))
+    if not ok:
+        print(f"MISMATCH (chunks) seed {seed}: cuts {cuts} env {c['env']} algo {c['algo']} sigma {c['sigma']}", flush=True)
+    return 0 if ok else 1
+
+
+def check_segments(spm, ctx, rng, c, text, ps, seed):
+    """A batch of haystacks back to back: the segmented scan == every segment scanned on its own by the brute-force engine."""
+    n = c["n"]
+    offs = sorted({0, n, *[int(x) for x in rng.integers(1, n, int(rng.integers(1, 12)))]})
+    got = _sorted(spm.scan_segments(ctx, text, ps, offs, engine=spm.ENGINE_FILTER, max_hits=1 << 24).view().copy())
+    parts = []
+    for b, e in zip(offs[:-1], offs[1:]):
+        parts.append(spm.scan(ctx, text, ps, b, e, engine=spm.ENGINE_BRUTE, max_hits=1 << 24).view().copy())
+    want = _sorted(np.concatenate(parts))
+    ok = np.array_equal(got, want)
+    if not ok:
+        print(f"MISMATCH (segments) seed {seed}: {len(got)} vs {len(want)} hits, offsets {offs} env {c['env']} algo {c['algo']} "
+              f"sigma {c['sigma']}", flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
@@ -104,6 +146,19 @@ def main():
                 seed += 1
                 continue
             bs = ps.build_stats()
+            variant = rng.random()
+            if variant < 0.12 and c["algo"] != spm.ALGO_HORSPOOL:
+                bad += check_chunks(spm, ctx, rng, c, text, ps, seed)
+                kinds["chunks"] = kinds.get("chunks", 0) + 1
+                done += 1
+                seed += 1
+                continue
+            if variant < 0.24:
+                bad += check_segments(spm, ctx, rng, c, text, ps, seed)
+                kinds["segments"] = kinds.get("segments", 0) + 1
+                done += 1
+                seed += 1
+                continue
             lo = int(rng.integers(0, c["n"] // 3)) if rng.random() < 0.4 else 0
             hi = int(rng.integers(2 * c["n"] // 3, c["n"])) if rng.random() < 0.4 else c["n"]
             lc = bool(rng.random() < 0.5)
