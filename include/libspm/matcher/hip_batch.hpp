@@ -65,19 +65,40 @@ public:
         if (spm_hip_text_upload(ctx, ranks, n, _sigma, &t) != SPM_OK)
             hip::fatal("spm_hip_text_upload", ctx);
         hip::text_ptr text{t};
+        run_on(text.get(), 0, n, callback);
+    }
+
+    // the whole needle set against a haystack (or a slice of one) that is resident in HBM: no upload, one scan
+    template <typename callback_t>
+    void operator()(hip::resident_haystack const & haystack, callback_t && callback) noexcept
+    {
+        if (_lengths.empty() || haystack.empty())
+            return;
+        if (haystack.sigma() != _sigma) {
+            std::fprintf(stderr, "libspm (MI355X back-end): the resident haystack's alphabet (%u symbols) is not the needles' (%u)\n",
+                         haystack.sigma(), _sigma);
+            std::abort();
+        }
+        run_on(haystack.text(), haystack.begin_offset(), haystack.size(), callback);
+    }
+
+private:
+    template <typename callback_t>
+    void run_on(spm_text * text, std::size_t base, std::size_t n, callback_t && callback) noexcept
+    {
+        spm_ctx * ctx = hip::default_context();
         spm_hit const * rec = nullptr;
         std::uint64_t cnt = 0;
         hip::hits_ptr hits = hip::scan_all_hits(
             ctx, spm_scan_opts{},
             [&](spm_scan_opts const & o, spm_hits ** h) {
-                return spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &o, nullptr, nullptr, h);
+                return spm_hip_scan(ctx, text, base, base + n, _patterns.get(), &o, nullptr, nullptr, h);
             },
             rec, cnt, "spm_hip_scan");
         for (std::uint64_t i = 0; i < cnt; ++i) {
             std::size_t const m = _lengths[rec[i].pattern];
-            finder f = reports_begin_v ? finder{static_cast<std::size_t>(rec[i].pos), static_cast<std::size_t>(rec[i].pos) + m, n, 0}
-                                       : finder{rec[i].pos >= m ? static_cast<std::size_t>(rec[i].pos) - m : 0,
-                                                static_cast<std::size_t>(rec[i].pos), n, rec[i].score};
+            std::size_t const pos = static_cast<std::size_t>(rec[i].pos) - base;
+            finder f = reports_begin_v ? finder{pos, pos + m, n, 0} : finder{pos >= m ? pos - m : 0, pos, n, rec[i].score};
             callback(static_cast<std::size_t>(rec[i].pattern), f);
         }
     }

@@ -15,6 +15,9 @@
 #include <ranges>
 #include <vector>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <libspm/hip/context.hpp>
 #include <libspm/seqan/container_adapter.hpp>
 #include <libspm/matcher/concept.hpp>
@@ -63,6 +66,63 @@ namespace detail
         return v;
     }
 } // namespace detail
+
+namespace hip
+{
+// A haystack that stays in HBM between calls.  The reference's call sites hand the matcher a host range every time
+// (seqan_pattern_base.hpp:40-47) -- here that is one upload per call; a traverser that scans the same sequence with many
+// matchers, or chunk by chunk with a restorable one, uploads it ONCE and passes this object instead:
+//     spm::hip::resident_haystack hs{sequence};      matcher(hs, callback);      matcher(hs.slice(b, e), callback);
+// Copies and slices share the device buffer; a slice is a haystack of its own (positions count from its first symbol,
+// nothing before it is seen -- exactly what passing the sub-range as a host view would do).
+class resident_haystack
+{
+    std::shared_ptr<spm_text> _text{};
+    std::size_t _begin{0}, _end{0};
+    std::uint32_t _sigma{4};
+
+public:
+    resident_haystack() = default;
+    template <std::ranges::input_range range_t>
+        requires(!std::same_as<std::remove_cvref_t<range_t>, resident_haystack>)
+    explicit resident_haystack(range_t && sequence)
+    {
+        _sigma = detail::sigma_of<std::ranges::range_value_t<range_t>>();
+        std::vector<std::uint8_t> const ranks = detail::to_ranks(sequence);
+        spm_text * t = nullptr;
+        std::uint8_t const dummy = 0;
+        if (spm_hip_text_upload(default_context(), ranks.empty() ? &dummy : ranks.data(), ranks.size(), _sigma, &t) != SPM_OK)
+            fatal("spm_hip_text_upload", default_context());
+        _text = std::shared_ptr<spm_text>(t, text_deleter{});
+        _end = ranks.size();
+    }
+    // ranks that already live in HBM (one byte per symbol, 16-byte aligned; validated once): borrowed, not copied
+    static resident_haystack wrap(void const * device_ranks, std::size_t n, std::uint32_t sigma)
+    {
+        resident_haystack h;
+        spm_text * t = nullptr;
+        if (spm_hip_text_wrap(default_context(), device_ranks, n, sigma, &t) != SPM_OK)
+            fatal("spm_hip_text_wrap", default_context());
+        h._text = std::shared_ptr<spm_text>(t, text_deleter{});
+        h._end = n;
+        h._sigma = sigma;
+        return h;
+    }
+    resident_haystack slice(std::size_t begin, std::size_t end) const noexcept
+    {
+        resident_haystack h = *this;
+        h._begin = std::min(_begin + begin, _end);
+        h._end = std::min(_begin + std::max(begin, end), _end);
+        return h;
+    }
+    std::size_t size() const noexcept { return _end - _begin; }
+    bool empty() const noexcept { return _end == _begin; }
+    std::uint32_t sigma() const noexcept { return _sigma; }
+    spm_text * text() const noexcept { return _text.get(); }
+    std::size_t begin_offset() const noexcept { return _begin; }
+    std::size_t end_offset() const noexcept { return _end; }
+};
+} // namespace hip
 
 template <typename derived_t>
 class hip_pattern_base
@@ -135,27 +195,48 @@ public:
         }
     }
 
+    // the same call on a haystack (or a slice of one) that is resident in HBM: no upload
+    template <typename callback_t>
+    void operator()(hip::resident_haystack const & haystack, callback_t && callback) noexcept
+    {
+        if (haystack.sigma() != _sigma && !_needle.empty()) {
+            std::fprintf(stderr, "libspm (MI355X back-end): the resident haystack's alphabet (%u symbols) is not the needle's (%u)\n",
+                         haystack.sigma(), _sigma);
+            std::abort();
+        }
+        static_cast<derived_t *>(this)->run_on(haystack.text(), haystack.begin_offset(), haystack.size(), callback);
+    }
+
     bool empty() const noexcept { return _needle.empty(); }
 
 protected:
-    // default run(): fresh matcher every call (a fresh seqan2::Finder re-initialises the pattern)
     template <typename callback_t>
     void run(std::uint8_t const * ranks, std::size_t n, callback_t && callback) noexcept
     {
         hip::text_ptr text = upload(ranks, n);
-        spm_hit const * rec = nullptr;
-        std::uint64_t cnt = 0;
-        hip::hits_ptr hits = scan_text(text.get(), 0, n, nullptr, nullptr, rec, cnt);
-        for (std::uint64_t i = 0; i < cnt; ++i)
-            callback(make_finder(rec[i], n));
+        static_cast<derived_t *>(this)->run_on(text.get(), 0, n, callback);
     }
 
-    finder make_finder(spm_hit const & h, std::size_t n) const noexcept
+    // default run_on(): fresh matcher every call (a fresh seqan2::Finder re-initialises the pattern); the haystack is
+    // text[base, base + n)
+    template <typename callback_t>
+    void run_on(spm_text * text, std::size_t base, std::size_t n, callback_t && callback) noexcept
+    {
+        if (text == nullptr || n == 0)
+            return;
+        spm_hit const * rec = nullptr;
+        std::uint64_t cnt = 0;
+        hip::hits_ptr hits = scan_text(text, base, base + n, nullptr, nullptr, rec, cnt);
+        for (std::uint64_t i = 0; i < cnt; ++i)
+            callback(make_finder(rec[i], n, base));
+    }
+
+    // (hit positions arrive relative to text[0]; the finder speaks in haystack coordinates)
+    finder make_finder(spm_hit const & h, std::size_t n, std::size_t base = 0) const noexcept
     {
         std::size_t const m = _needle.size();
-        return derived_t::reports_begin
-                   ? finder{static_cast<std::size_t>(h.pos), static_cast<std::size_t>(h.pos) + m, n, 0}
-                   : finder{h.pos >= m ? static_cast<std::size_t>(h.pos) - m : 0, static_cast<std::size_t>(h.pos), n, h.score};
+        std::size_t const pos = static_cast<std::size_t>(h.pos) - base;
+        return derived_t::reports_begin ? finder{pos, pos + m, n, 0} : finder{pos >= m ? pos - m : 0, pos, n, h.score};
     }
 
 private:

@@ -48,6 +48,7 @@ class restorable_base : public hip_pattern_base<derived_t>
     matcher_state _state{};
     // replay context, valid only while the callbacks of one operator() call run
     mutable spm_text * _replay_text{nullptr};
+    mutable std::size_t _replay_base{0}; // where the haystack of this call begins in _replay_text (a slice of a resident one)
     mutable matcher_state _cap_state{}; // state after text[0, _cap_pos) ...
     mutable std::size_t _cap_pos{0};
     mutable std::size_t _replay_end{0}; // end of the hit whose callback is running
@@ -61,13 +62,19 @@ class restorable_base : public hip_pattern_base<derived_t>
         _state = matcher_state{std::move(b)};
     }
 
+    // the haystack (a chunk, usually) is text[base, base + n): uploaded by the caller of this function -- hip_pattern_base::
+    // run() for a host range, nobody for a spm::hip::resident_haystack, whose chunks are slices of one resident sequence
     template <typename callback_t>
-    void run(std::uint8_t const * ranks, std::size_t n, callback_t && callback) noexcept
+    void run_on(spm_text * text_handle, std::size_t base, std::size_t n, callback_t && callback) noexcept
     {
         n = static_cast<derived_t *>(this)->bound(n);
-        if (this->_needle.empty())
+        if (this->_needle.empty() || text_handle == nullptr)
             return; // empty needle: nothing to find (myers_prefix_matcher_restorable.hpp:39,52)
-        hip::text_ptr text = this->upload(ranks, n);
+        struct
+        {
+            spm_text * t;
+            spm_text * get() const noexcept { return t; }
+        } const text{text_handle};
         std::size_t from = 0;
         for (;;) {
             matcher_state const entry = _state;
@@ -75,14 +82,15 @@ class restorable_base : public hip_pattern_base<derived_t>
             spm_hit const * rec = nullptr;
             std::uint64_t cnt = 0;
             hip::hits_ptr hits =
-                this->scan_text(text.get(), from, n, entry.blob().data(), out.blob().data(), rec, cnt);
+                this->scan_text(text.get(), base + from, base + n, entry.blob().data(), out.blob().data(), rec, cnt);
             _state = out; // state after the last symbol; what capture() returns once the call has finished
             _replay_text = text.get();
+            _replay_base = base;
             _cap_state = entry;
             _cap_pos = from;
             bool restarted = false;
             for (std::uint64_t i = 0; i < cnt && !restarted; ++i) {
-                finder const f = this->make_finder(rec[i], n);
+                finder const f = this->make_finder(rec[i], n, base);
                 _replay_end = f.end_position();
                 _restore_pending = false;
                 callback(f);
@@ -115,7 +123,8 @@ public:
             spm_hit const * rec = nullptr;
             std::uint64_t cnt = 0;
             hip::hits_ptr ignored =
-                this->scan_text(_replay_text, _cap_pos, _replay_end, _cap_state.blob().data(), at.blob().data(), rec, cnt);
+                this->scan_text(_replay_text, _replay_base + _cap_pos, _replay_base + _replay_end, _cap_state.blob().data(),
+                                at.blob().data(), rec, cnt);
             _cap_state = std::move(at);
             _cap_pos = _replay_end;
         }

@@ -444,6 +444,79 @@ static void paused_scan_cases()
     }
 }
 
+static void resident_haystack_cases()
+{
+    // the reference's cases again with the haystack uploaded ONCE (spm::hip::resident_haystack) and handed to every
+    // matcher -- whole, and as slices for the chunk-of-13 capture/restore walk (myers_matcher_restorable_test.cpp:55-74)
+    spm::hip::resident_haystack const hs{haystack};
+    EXPECT_EQ(hs.size(), haystack.size());
+    {
+        std::vector<std::size_t> a, b, c;
+        spm::horspool_matcher{needle}(hs, [&](auto const & f) { a.push_back(seqan2::beginPosition(f)); });
+        spm::shiftor_matcher{needle}(hs, [&](auto const & f) { b.push_back(seqan2::beginPosition(f)); });
+        spm::myers_matcher{needle, 1}(hs, [&](auto const & f) { c.push_back(seqan2::endPosition(f)); });
+        EXPECT_TRUE(std::ranges::equal(a, std::vector<std::size_t>{9, 20, 31}));
+        EXPECT_TRUE(std::ranges::equal(b, std::vector<std::size_t>{9, 20, 31}));
+        EXPECT_TRUE(std::ranges::equal(c, std::vector<std::size_t>{13, 14, 15, 24, 25, 26, 35, 36, 37}));
+    }
+    { // a slice is a haystack of its own: positions from its first symbol, nothing before it is seen
+        std::vector<std::size_t> got, want;
+        spm::myers_matcher{needle, 1}(hs.slice(11, 40), [&](auto const & f) { got.push_back(seqan2::endPosition(f)); });
+        sequence_t const sub{haystack.begin() + 11, haystack.begin() + 40};
+        spm::myers_matcher{needle, 1}(sub, [&](auto const & f) { want.push_back(seqan2::endPosition(f)); });
+        EXPECT_TRUE(got == want && !want.empty());
+        std::vector<std::size_t> none;
+        spm::shiftor_matcher{needle}(hs.slice(10, 13), [&](auto const & f) { none.push_back(seqan2::beginPosition(f)); });
+        EXPECT_TRUE(none.empty());
+        EXPECT_EQ(hs.slice(40, 100).size(), std::size_t{4});
+        EXPECT_TRUE(hs.slice(7, 3).empty());
+    }
+    { // chunks of 13 as slices, restore(state) before and capture() after each
+        std::size_t const chunk_size{13};
+        auto matcher = spm::restorable_myers_matcher{needle, 1u};
+        auto state = matcher.capture();
+        std::vector<std::size_t> actual{};
+        for (std::size_t offset = 0; offset < haystack.size(); offset += chunk_size) {
+            matcher.restore(state);
+            matcher(hs.slice(offset, offset + chunk_size),
+                    [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder) + offset); });
+            state = matcher.capture();
+        }
+        EXPECT_TRUE(std::ranges::equal(actual, std::vector<std::size_t>{13, 14, 15, 24, 25, 26, 35, 36, 37}));
+    }
+    { // capture() inside a callback on a slice, resumed on the rest of the resident sequence
+        auto matcher = spm::restorable_myers_matcher{needle, 1u};
+        spm::matcher_state_t<decltype(matcher)> at_second{};
+        std::size_t second_end = 0;
+        int seen = 0;
+        matcher(hs.slice(5, 44), [&](auto const & finder) {
+            if (++seen == 2) {
+                at_second = spm::capture(matcher);
+                second_end = seqan2::endPosition(finder) + 5;
+            }
+        });
+        EXPECT_EQ(second_end, std::size_t{14});
+        auto resumed = spm::restorable_myers_matcher{needle, 1u};
+        spm::restore(resumed, at_second);
+        std::vector<std::size_t> actual{};
+        resumed(hs.slice(second_end, 44), [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder) + second_end); });
+        EXPECT_TRUE(std::ranges::equal(actual, std::vector<std::size_t>{15, 24, 25, 26, 35, 36, 37}));
+    }
+    { // the batch front-end on the resident haystack == on the host range
+        sequence_t const needle2 = "TGACTAGCAC"_dna4;
+        std::vector<sequence_t> const needles{needle, needle2, "ACGT"_dna4};
+        auto batch = spm::batch_myers_matcher{needles, 1};
+        std::vector<std::pair<std::size_t, std::size_t>> got, want, got_s, want_s;
+        batch(hs, [&](std::size_t i, auto const & f) { got.emplace_back(i, seqan2::endPosition(f)); });
+        batch(haystack, [&](std::size_t i, auto const & f) { want.emplace_back(i, seqan2::endPosition(f)); });
+        EXPECT_TRUE(got == want && want.size() > 9);
+        batch(hs.slice(3, 30), [&](std::size_t i, auto const & f) { got_s.emplace_back(i, seqan2::endPosition(f)); });
+        sequence_t const sub{haystack.begin() + 3, haystack.begin() + 30};
+        batch(sub, [&](std::size_t i, auto const & f) { want_s.emplace_back(i, seqan2::endPosition(f)); });
+        EXPECT_TRUE(got_s == want_s && !want_s.empty());
+    }
+}
+
 int main()
 {
     horspool_cases();
@@ -457,6 +530,7 @@ int main()
     alphabet_cases();
     container_adapter_cases();
     paused_scan_cases();
+    resident_haystack_cases();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures;
 }
