@@ -124,12 +124,34 @@ public:
         if (spm_hip_text_upload(ctx, ranks, n, _sigma, &t) != SPM_OK)
             hip::fatal("spm_hip_text_upload", ctx);
         hip::text_ptr text{t};
+        run_on(text.get(), 0, n, callback);
+    }
+
+    // the same on a haystack (or a slice of one) that is resident in HBM (hip_pattern_base.hpp): no upload
+    template <typename callback_t>
+    void operator()(hip::resident_haystack const & haystack, callback_t && callback) noexcept
+    {
+        if (_seeds.empty() || haystack.empty())
+            return;
+        if (haystack.sigma() != _sigma) {
+            std::fprintf(stderr, "libspm (MI355X back-end): the resident haystack's alphabet (%u symbols) is not the needles' (%u)\n",
+                         haystack.sigma(), _sigma);
+            std::abort();
+        }
+        run_on(haystack.text(), haystack.begin_offset(), haystack.size(), callback);
+    }
+
+private:
+    template <typename callback_t>
+    void run_on(spm_text * text, std::size_t base, std::size_t n, callback_t && callback) noexcept
+    {
+        spm_ctx * ctx = hip::default_context();
         spm_hit const * rec = nullptr;
         std::uint64_t cnt = 0;
         hip::hits_ptr hits = hip::scan_all_hits(
             ctx, spm_scan_opts{},
             [&](spm_scan_opts const & o, spm_hits ** h) {
-                return spm_hip_scan(ctx, text.get(), 0, n, _patterns.get(), &o, nullptr, nullptr, h);
+                return spm_hip_scan(ctx, text, base, base + n, _patterns.get(), &o, nullptr, nullptr, h);
             },
             rec, cnt, "spm_hip_scan");
         // seed hits in ascending haystack position (ties: needle order, then offset)
@@ -137,10 +159,13 @@ public:
         std::stable_sort(order.begin(), order.end(), [](spm_hit const & a, spm_hit const & b) { return a.pos < b.pos; });
         for (spm_hit const & x : order) {
             _position = {_seeds[x.pattern].index, _seeds[x.pattern].offset, _q};
-            finder f{static_cast<std::size_t>(x.pos), static_cast<std::size_t>(x.pos) + _q, n, 0};
+            std::size_t const pos = static_cast<std::size_t>(x.pos) - base;
+            finder f{pos, pos + _q, n, 0};
             callback(f);
         }
     }
+
+public:
 
     constexpr auto position() const noexcept { return _position; }
     bool empty() const noexcept { return _seeds.empty(); }

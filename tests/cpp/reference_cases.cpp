@@ -502,6 +502,19 @@ static void resident_haystack_cases()
         resumed(hs.slice(second_end, 44), [&](auto const & finder) { actual.push_back(seqan2::endPosition(finder) + second_end); });
         EXPECT_TRUE(std::ranges::equal(actual, std::vector<std::size_t>{15, 24, 25, 26, 35, 36, 37}));
     }
+    { // pigeonhole seed hits (pigeonhole_matcher_test.cpp:54-85) on the resident haystack and on a slice of it
+        sequence_t const needle2 = "TGACTAGCAC"_dna4;
+        std::vector<sequence_t> const needles{needle, needle2};
+        auto matcher = spm::pigeonhole_matcher{needles};
+        std::vector<std::size_t> got, want, got_s, want_s;
+        matcher(hs, [&](auto const & f) { got.push_back(seqan2::beginPosition(f)); });
+        matcher(haystack, [&](auto const & f) { want.push_back(seqan2::beginPosition(f)); });
+        EXPECT_TRUE(got == want && std::ranges::equal(want, std::vector<std::size_t>{3, 8, 9, 14, 19, 20, 25, 30, 31, 36}));
+        matcher(hs.slice(2, 33), [&](auto const & f) { got_s.push_back(seqan2::beginPosition(f)); });
+        sequence_t const sub{haystack.begin() + 2, haystack.begin() + 33};
+        matcher(sub, [&](auto const & f) { want_s.push_back(seqan2::beginPosition(f)); });
+        EXPECT_TRUE(got_s == want_s && !want_s.empty());
+    }
     { // the batch front-end on the resident haystack == on the host range
         sequence_t const needle2 = "TGACTAGCAC"_dna4;
         std::vector<sequence_t> const needles{needle, needle2, "ACGT"_dna4};
