@@ -5,8 +5,6 @@
 
 namespace
 {
-const scan_tuning *g_tune = nullptr; // the knobs of the scan being launched (set by run_filter; launches are host-serial per context)
-scan_tuning g_tune_default;
 template <int NWN>
 void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 {
@@ -21,12 +19,12 @@ void launch_verify_nw(const verify_params &V, dim3 grid, hipStream_t s)
 }
 
 template <int G, int NB>
-void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid, hipStream_t s)
+void launch_verify_wave_g(const scan_tuning &T, verify_params V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid, hipStream_t s)
 {
     // One wave per workgroup: a scan leaves a few thousand long bands, i.e. far fewer busy waves than the GPU has SIMDs,
     // and each is a serial chain ~1500 steps long.  With four-wave workgroups filled in order, the dispatcher packed the
     // busy waves four to a SIMD on a third of the CUs and left the rest idle.
-    const uint32_t threads = (uint32_t)std::max(64, std::min(256, (*(g_tune ? g_tune : &g_tune_default)).verify_wave_threads));
+    const uint32_t threads = (uint32_t)std::max(64, std::min(256, T.verify_wave_threads));
     grid.x *= 256 / threads;
     const uint32_t n_slots = 2 * V.max_k + 1 + V.max_span;
     // text window of one candidate: cold start |P| + k symbols before the first end position, then the end positions
@@ -34,33 +32,33 @@ void launch_verify_wave_g(verify_params V, const uint32_t *peq_bot, uint32_t max
     const size_t per_group = ((n_slots * 2 + 15) & ~15u) + V.wave_text;
     size_t lds = (size_t)(threads / 64) * (64 / G) * per_group;
     // (diagnostics: a larger LDS claim per workgroup caps how many of them a CU takes at once)
-    lds = std::max<size_t>(lds, (size_t)std::max(0, std::min(160, (*(g_tune ? g_tune : &g_tune_default)).verify_wave_lds_kb)) * 1024);
+    lds = std::max<size_t>(lds, (size_t)std::max(0, std::min(160, T.verify_wave_lds_kb)) * 1024);
     hipFuncSetAttribute((const void *)verify_wave_kernel<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((verify_wave_kernel<G, NB>), grid, dim3(threads), lds, s, V, peq_bot);
 }
 
 // long needles: NB 32-row blocks per lane, G = lanes per band >= blocks of the longest needle / NB.  SPM_HIP_VERIFY_WAVE_NB=2:
 // two blocks per lane from 17 blocks on (four |P| = 1024 bands share a wave instead of two).
-void launch_verify_wave(uint32_t n_blocks, const verify_params &V, const uint32_t *peq_bot, uint32_t max_m, dim3 grid,
-                        hipStream_t s)
+void launch_verify_wave(const scan_tuning &T, uint32_t n_blocks, const verify_params &V, const uint32_t *peq_bot, uint32_t max_m,
+                        dim3 grid, hipStream_t s)
 {
     // (measured on C5, 2 798 bands of |P| = 1024: one block per lane 0.300 ms, two 0.358 -- a step is a chain of dependent
     // instructions, its latency and not its issue slots set the pace, and the second block lengthens the chain.)
-    const bool two = (*(g_tune ? g_tune : &g_tune_default)).verify_wave_nb >= 2;
+    const bool two = T.verify_wave_nb >= 2;
     if (n_blocks <= 8)
-        launch_verify_wave_g<8, 1>(V, peq_bot, max_m, grid, s);
+        launch_verify_wave_g<8, 1>(T, V, peq_bot, max_m, grid, s);
     else if (n_blocks <= 16)
-        launch_verify_wave_g<16, 1>(V, peq_bot, max_m, grid, s);
+        launch_verify_wave_g<16, 1>(T, V, peq_bot, max_m, grid, s);
     else if (n_blocks <= 32) {
         if (two)
-            launch_verify_wave_g<16, 2>(V, peq_bot, max_m, grid, s);
+            launch_verify_wave_g<16, 2>(T, V, peq_bot, max_m, grid, s);
         else
-            launch_verify_wave_g<32, 1>(V, peq_bot, max_m, grid, s);
+            launch_verify_wave_g<32, 1>(T, V, peq_bot, max_m, grid, s);
     } else {
         if (two)
-            launch_verify_wave_g<32, 2>(V, peq_bot, max_m, grid, s);
+            launch_verify_wave_g<32, 2>(T, V, peq_bot, max_m, grid, s);
         else
-            launch_verify_wave_g<64, 1>(V, peq_bot, max_m, grid, s);
+            launch_verify_wave_g<64, 1>(T, V, peq_bot, max_m, grid, s);
     }
 }
 
@@ -110,7 +108,6 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
 
 int run_filter(const scan_args &A)
 {
-    g_tune = &A.tune;
     spm_ctx *ctx = A.ctx;
     const spm_patterns *ps = A.ps;
     spm_hits *H = A.hits;
@@ -610,7 +607,7 @@ int run_filter(const scan_args &A)
         // (the resolve kernel reported the hits)
     } else if (use_wave) {
         // one verification is a ~1400-step serial chain: enough waves that every band gets its own right away
-        launch_verify_wave(nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
+        launch_verify_wave(A.tune, nwn, V, ps->d_peq_bot, ps->max_m, dim3(ctx->n_cu * 16), ctx->stream);
     } else {
         if (nwn > 8)
             nwn = ps->NW; // power of two beyond 8 words

@@ -47,8 +47,8 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
         SPM_HIP_CHECK(none, hipEventCreateWithFlags(&ctx->stage_ev[e], hipEventDisableTiming));
     // the first host-to-device copy of a process sets up the copy engine's queue (7 of the 8 ms of uploading the 2 MB of a
     // 1024-needle set): done here, with the first device-to-host one
-    if (hipMalloc(&ctx->d_scratch, (size_t)64 << 20) == hipSuccess) {
-        ctx->scratch_bytes = (size_t)64 << 20;
+    if (hipMalloc(&ctx->d_scratch, (size_t)128 << 20) == hipSuccess) { // (the first scan of 1 GiB against 1 024 needles asks for 91 MB)
+        ctx->scratch_bytes = (size_t)128 << 20;
         memset(ctx->h_stage, 0, ctx->stage_half); // (a copy of the size the uploads use: small ones take another path)
         (void)hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, ctx->stage_half, hipMemcpyHostToDevice, ctx->stream);
         (void)hipEventRecord(ctx->stage_ev[0], ctx->stream);
@@ -66,6 +66,11 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
                   hipMalloc(&b.d_count, 16 * sizeof(unsigned long long)) == hipSuccess;
         for (int e = 0; e < 4 && ok; ++e)
             ok = hipEventCreate(&b.ev[e]) == hipSuccess;
+        // (what a deferred scan adds: its own pinned counter block -- a pinned allocation costs ~0.1 ms -- and an event)
+        if (ok && hipHostMalloc(reinterpret_cast<void **>(&b.h_c), 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+            b.h_c = nullptr;
+        if (ok && hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming) != hipSuccess)
+            b.ev_done = nullptr;
         if (ok && hipMemsetAsync(b.d_count, 0, 16 * sizeof(unsigned long long), ctx->stream) == hipSuccess) {
             b.zeroed = true;
             ctx->pool.push_back(b);
@@ -75,6 +80,10 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
             for (int e = 0; e < 4; ++e)
                 if (b.ev[e])
                     hipEventDestroy(b.ev[e]);
+            if (b.h_c)
+                hipHostFree(b.h_c);
+            if (b.ev_done)
+                hipEventDestroy(b.ev_done);
         }
     }
     spm_warm_text_kernels();
