@@ -17,7 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def make_case(rng, spm):
+def make_case(rng, spm, big=0.0):
     n = int(rng.choice([1 << 18, 1 << 20, 1 << 21, 3 * (1 << 19) + 12345]))
     sigma = int(rng.choice([4, 4, 4, 5]))
     T = rng.integers(0, 4, n, dtype=np.uint8)
@@ -36,6 +36,8 @@ def make_case(rng, spm):
             T[at:at + int(rng.integers(1, 30))] = 3
     algo = int(rng.choice([spm.ALGO_MYERS, spm.ALGO_MYERS, spm.ALGO_MYERS, spm.ALGO_SHIFTOR, spm.ALGO_HORSPOOL]))
     n_needles = int(rng.choice([3, 64, 65, 500, 3000, 9000]))
+    if rng.random() < big:      # sets that take the dense pass by themselves (more keys than one fingerprint table holds)
+        n_needles = int(rng.choice([16000, 40000, 100000]))
     kmax = 0 if algo != spm.ALGO_MYERS else int(rng.choice([0, 1, 2, 3, 5]))
     Lmin = int(rng.choice([24, 40, 64, 100]))
     Lmax = Lmin if rng.random() < 0.5 else Lmin + int(rng.integers(1, 120))
@@ -124,6 +126,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", type=float, default=0.0, help="share of cases with 16 000 .. 100 000 needles")
     args = ap.parse_args()
     import torch
     torch.zeros(1, device="cuda")      # torch's HIP runtime first (tests/conftest.py says why)
@@ -136,7 +139,7 @@ def main():
     kinds = {}
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
-        c = make_case(rng, spm)
+        c = make_case(rng, spm, args.big)
         os.environ.update(c["env"])
         try:
             text = ctx.upload(c["T"], sigma=c["sigma"])
