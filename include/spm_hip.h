@@ -84,13 +84,14 @@ typedef struct spm_scan_opts {
 
 #define SPM_SCAN_IGNORE_PACKED 1u /* do not use the text's 2-bit shadow even if it has one */
 /* Deferred completion.  spm_hip_scan normally returns when it KNOWS the scan is complete: it reads the device counters
- * back once (one host synchronisation), because a list that proved too small means another attempt.  With this flag the
- * call returns as soon as the kernels are enqueued whenever the scan cannot need a second attempt on the device side
- * alone -- today: exact needle sets whose hits come straight from the resolve kernel (Shift-Or / Horspool sets, config
- * C2) --; the counters are read at the first accessor that needs the hit count (view, device, copy_device, copy_fused,
- * stats, destroy), and a scan that does need attention is repeated there, synchronously.  The text and the needle set
- * must stay alive until then.  Other scans ignore the flag.  With spm_hip_hits_copy_fused_device a step of a scan loop
- * has no host synchronisation at all: the GPU never waits for the host between steps. */
+ * back once (one host synchronisation), because a list that proved too small means another attempt.  With this flag a
+ * whole (unsegmented), stateless scan through the seed filter returns as soon as its kernels are enqueued; the counters are
+ * read at the first accessor that needs the hit count (view, device, copy_device, copy_fused, stats, destroy), and a scan
+ * that does need attention -- a list overflowed, a span gave up, or an EARLIER deferred scan left the context's band table
+ * in a state this one could not trust -- is repeated there, synchronously, retries and fallbacks included.  The text and
+ * the needle set must stay alive until then.  Stateful and segmented scans and the brute-force engine ignore the flag.
+ * With spm_hip_hits_copy_fused_device a step of a scan loop has no host synchronisation at all: the GPU never waits for
+ * the host between steps (the status word of its header says whether the host has to look). */
 #define SPM_SCAN_DEFER 2u
 
 /* Per-scan device timings, HIP events on the context's stream (ms). */

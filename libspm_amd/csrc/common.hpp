@@ -53,6 +53,7 @@ struct spm_ctx
     ulonglong2 *d_band_tab = nullptr; // {key, value} per slot (filter.hpp: band_value)
     uint64_t band_slots = 0;
     bool band_dirty = false;
+    uint32_t *d_table_poison = nullptr; // device flag: the table holds slots a scan left behind (filter.hpp: resolve_params)
     // pinned staging of needle-set uploads: two halves, so the host fills one while the other travels (patterns.hip)
     uint8_t *h_stage = nullptr;
     size_t stage_half = 0;

@@ -1056,6 +1056,12 @@ struct resolve_params
     spm_hit *hits;
     unsigned long long *hit_counter, *overflow;
     uint64_t hit_cap;
+    // The band table is shared by the scans of a context and must be EMPTY when a scan starts (a slot left behind by an
+    // earlier scan makes this one take a band for "already listed" and never verify it).  A scan whose band list or table
+    // overflows leaves such slots; the host empties the table before the next scan -- unless that scan was launched before
+    // the host looked (deferred completion, SPM_SCAN_DEFER).  So the overflow is also recorded HERE, on the device, where it
+    // sticks until the host has emptied the table: a scan that finds it set declares itself void.
+    uint32_t *table_poison;
 };
 
 // Band table slot: .x = key (kBandEmpty = all ones: free), .y = value kept so that a free slot is ALL ONES (one memset
@@ -1309,8 +1315,10 @@ __device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue
                 s2 = (s2 + 1) & R.table_mask;
             }
         }
-        if (!placed)
+        if (!placed) {
             atomicAdd(&R.counters[2], 1ull); // table full: the host starts over with more room
+            *R.table_poison = 1u;
+        }
         else if (R.overlap)
             atomicAdd(&R.band_tab[s2].y, 1ull);
         else
@@ -1348,7 +1356,8 @@ __device__ __forceinline__ void insert_bands(const resolve_params &R, band_queue
             br.band = (uint32_t)(bkey & ((1ull << R.band_bits) - 1));
             R.bands[idx] = br;
         } else {
-            atomicAdd(&R.counters[2], 1ull); // band list full
+            atomicAdd(&R.counters[2], 1ull); // band list full: the slot this lane claimed is never given back
+            *R.table_poison = 1u;
         }
     }
     C.used += nn;
@@ -1557,6 +1566,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
     }
     if (n > R.surv_cap)
         n = R.surv_cap;
+    if (!R.exact_hits && __hip_atomic_load(R.table_poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        // an earlier scan left slots in the band table and the host has not emptied it yet: this scan is void
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicAdd(&R.counters[2], 1ull);
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63;
     resolve_wave S;
     S.Q = &pair_queues[threadIdx.x >> 6];

@@ -100,6 +100,7 @@ struct scan_tuning
     int resolve_surv_per_wg = 1024;
     int verify_runs = 1;
     int verify_runs_min_bands = 65536;
+    int band_cap = 0;
     static scan_tuning from_env()
     {
         scan_tuning T;
@@ -131,6 +132,7 @@ struct scan_tuning
         T.resolve_surv_per_wg = env_int("SPM_HIP_RESOLVE_SURV_PER_WG", 1024);
         T.verify_runs = env_int("SPM_HIP_VERIFY_RUNS", 1);
         T.verify_runs_min_bands = env_int("SPM_HIP_VERIFY_RUNS_MIN_BANDS", 65536);
+        T.band_cap = env_int("SPM_HIP_FILTER_BAND_CAP", 0);
         return T;
     }
 };

@@ -173,8 +173,7 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
             rc = run_filter(A);
             if (rc != SPM_OK)
                 return rc;
-            if ((opts.flags & SPM_SCAN_DEFER) && A.exact_used && outer == 0 && attempt == 0 && !stateful && !segmented &&
-                !after_launch) {
+            if ((opts.flags & SPM_SCAN_DEFER) && outer == 0 && attempt == 0 && !stateful && !segmented && !after_launch) {
                 // deferred completion: the counters travel to this result's own pinned block; nobody waits for them now
                 if (!H->h_c)
                     SPM_HIP_CHECK(ctx, hipHostMalloc(&H->h_c, 16 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -185,6 +184,11 @@ int scan_impl(spm_ctx *ctx, const spm_text *text, uint64_t begin, uint64_t end, 
                 H->pending = true;
                 H->c_on_the_way = false;
                 H->d_count_cleared = false;
+                // Sets that go through the band table: the host cannot know yet whether this scan gave every slot back.
+                // It assumes so; if the band list or the table overflowed, the device remembers (resolve_params::
+                // table_poison), later scans declare themselves void until the host -- completing this one -- has emptied
+                // the table, and are repeated when they are completed in turn.
+                ctx->band_dirty = false;
                 H->d_text = text;
                 H->d_patterns = patterns;
                 H->d_begin = begin;
@@ -489,11 +493,14 @@ int spm_complete_deferred(spm_hits *h)
     h->stats.n_candidates = c[5];
     h->stats.n_bands = (uint32_t)std::min<unsigned long long>(c[7], 0xFFFFFFFFull);
     const bool clean = c[2] == 0 && c[6] == 0 && c[1] <= h->cand_cap;
-    if (clean || c[0] > h->cap) { // (more hits than the buffer takes is the caller's overflow, not a reason to scan again)
+    if (c[2] != 0)
+        ctx->band_dirty = true; // (a list or the table overflowed -- or the scan found the table poisoned: empty it next)
+    if (clean || (c[0] > h->cap && c[2] == 0)) { // (more hits than the buffer takes is the caller's overflow, not a reason to scan again)
         if (clean) {
             const spm_patterns *ps = h->d_patterns;
             ps->cand_hint = std::max<uint64_t>(ps->cand_hint, c[1]);
             ps->hit_hint = std::max<uint64_t>(ps->hit_hint, c[0]);
+            ps->band_hint = std::max<uint64_t>(ps->band_hint, c[3]);
             ps->scanned = true;
         }
         h->n = c[0];

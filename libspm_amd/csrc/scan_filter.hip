@@ -102,6 +102,7 @@ int ensure_band_table(spm_ctx *ctx, uint64_t slots)
             fprintf(stderr, "[spm_hip] band table grows to %.1f MiB: %.2f ms\n", slots * sizeof(ulonglong2) / 1048576.0, ms_since(t0));
     }
     SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_band_tab, 0xFF, ctx->band_slots * sizeof(ulonglong2), ctx->stream)); // all free
+    SPM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_table_poison, 0, 4, ctx->stream)); // (and known to be)
     ctx->band_dirty = false;
     return SPM_OK;
 }
@@ -138,8 +139,10 @@ int run_filter(const scan_args &A)
     // bands: at most one per candidate pair, usually far fewer (uniform text: 1 000 for 20 000 survivors; 1 % repeats: 1.6 M
     // for 6 M; 5 %: as many as survivors) -- a quarter of the survivor slots unless earlier scans needed more
     const uint64_t band_want = std::max<uint64_t>(surv_cap / 4, 2 * ps->band_hint);
-    const uint64_t band_cap = std::max<uint64_t>(band_want, 4096) * (A.band_scale ? A.band_scale : 1) +
-                              (uint64_t)ctx->n_cu * 32 * kChunkMin;
+    uint64_t band_cap = std::max<uint64_t>(band_want, 4096) * (A.band_scale ? A.band_scale : 1) +
+                        (uint64_t)ctx->n_cu * 32 * kChunkMin;
+    if (A.tune.band_cap > 0 && !A.band_scale) // (tests force the band-list-full path with it; a repeated attempt sizes itself)
+        band_cap = (uint64_t)A.tune.band_cap;
     uint64_t band_slots = 1u << 12;
     while (band_slots < 2 * band_cap)
         band_slots <<= 1;
@@ -528,6 +531,7 @@ int run_filter(const scan_args &A)
     R.hit_counter = H->d_count;
     R.overflow = H->d_count + 2;
     R.hit_cap = H->cap;
+    R.table_poison = ctx->d_table_poison;
     R.table_mask = (uint32_t)(band_slots - 1);
     R.bands = d_bands;
     R.band_cap = band_cap;

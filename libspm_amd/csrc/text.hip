@@ -57,6 +57,8 @@ extern "C" int spm_hip_init(int device, void *stream, spm_ctx **out)
     } else {
         ctx->d_scratch = nullptr;
     }
+    SPM_HIP_CHECK(none, hipMalloc(reinterpret_cast<void **>(&ctx->d_table_poison), 16));
+    SPM_HIP_CHECK(none, hipMemsetAsync(ctx->d_table_poison, 0, 16, ctx->stream));
     // what the first scan would otherwise allocate in front of its kernels (~0.1 ms per hipMalloc / event): a first piece of
     // scratch (survivor / band lists of a text up to ~2 GiB) and one recycled hit block of the default capacity
     {
@@ -114,6 +116,7 @@ extern "C" void spm_hip_destroy(spm_ctx *ctx)
     }
     for (auto &b : ctx->jst_pool)
         hipFree(b.first);
+    hipFree(ctx->d_table_poison);
     if (ctx->h_counters)
         hipHostFree(ctx->h_counters);
     if (ctx->h_stage)

@@ -165,11 +165,16 @@ def main():
             lo = int(rng.integers(0, c["n"] // 3)) if rng.random() < 0.4 else 0
             hi = int(rng.integers(2 * c["n"] // 3, c["n"])) if rng.random() < 0.4 else c["n"]
             lc = bool(rng.random() < 0.5)
-            got_h = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=lc, max_hits=1 << 24)
+            # (a third of the scans return before their kernels have finished -- SPM_SCAN_DEFER -- and are completed by the
+            # first accessor; two of them in a row now and then, so that one runs behind an unfinished other)
+            fl = spm.SCAN_DEFER if rng.random() < 0.33 else 0
+            if fl and rng.random() < 0.5:
+                spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=lc, max_hits=1 << 24, flags=fl).close()
+            got_h = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_FILTER, left_context=lc, max_hits=1 << 24, flags=fl)
             st = got_h.stats()
             got = got_h.view().copy()
             want = spm.scan(ctx, text, ps, lo, hi, engine=spm.ENGINE_BRUTE, left_context=lc, max_hits=1 << 24).view().copy()
-            kind = ("dense" if bs.dense else f"sparse x{bs.passes}") + (" fallback" if st.fallback_spans else "")
+            kind = ("dense" if bs.dense else f"sparse x{bs.passes}") + (" fallback" if st.fallback_spans else "") + (" deferred" if fl else "")
             kinds[kind] = kinds.get(kind, 0) + 1
             if not np.array_equal(got, want):
                 bad += 1

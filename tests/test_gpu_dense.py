@@ -278,3 +278,82 @@ def test_deferred_completion_of_exact_scans(spm, ctx):
     a = spm.scan(ctx, text, pm, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER).view()
     b = spm.scan(ctx, text, pm, engine=spm.ENGINE_FILTER).view()
     assert np.array_equal(a, b) and len(a) >= 64
+
+
+def _fused(buf, n_max):
+    head = buf[0].cpu().tolist()
+    n = min(head[0], n_max)
+    rec = buf[1:1 + n].cpu().numpy().view(np.uint8).reshape(-1, 16)
+    return head, np.sort(np.frombuffer(rec.tobytes(), dtype=[("pos", "<u8"), ("pattern", "<u4"), ("score", "<i4")]),
+                         order=["pattern", "pos"])
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_deferred_completion_of_myers_scans_and_the_poisoned_band_table(spm, ctx, dense):
+    """SPM_SCAN_DEFER for sets that go through the band table (Myers, k > 0).  Clean scans: back to back without the host,
+    results from the device-side fused copy.  A scan whose band list overflows leaves slots in the table the context's scans
+    share; scans launched behind it -- before the host has looked -- must not trust that table: they find the device-side
+    poison flag, declare themselves void (status 1) and are repeated when the host completes them."""
+    import torch
+    rng = np.random.default_rng(97 + dense)
+    n = 1 << 22
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    L, k = 100, 3
+    needles = []
+    for i in range(300):
+        at = int(rng.integers(0, n - L))
+        nd = T[at:at + L].copy()
+        for _ in range(i % (k + 1)):
+            nd[int(rng.integers(0, L))] = rng.integers(0, 4)
+        needles.append(nd)
+    text = ctx.upload(T)
+    if dense:
+        ps, _ = _dense(ctx, spm, spm.ALGO_MYERS, needles, k)
+    else:
+        ps = ctx.patterns(spm.ALGO_MYERS, needles, k=k)
+    want = spm.scan(ctx, text, ps, engine=spm.ENGINE_BRUTE).view()
+    assert len(want) >= 300
+    cap = 1 << 14
+    bufs = [torch.zeros((cap + 1, 2), dtype=torch.int64, device="cuda") for _ in range(4)]
+
+    def deferred(buf, **env):
+        os.environ.update({k_: str(v) for k_, v in env.items()})
+        try:
+            h = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER, flags=spm.SCAN_DEFER)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+        h.copy_fused_device(buf.data_ptr(), cap)
+        return h
+
+    # clean: four scans enqueued back to back, nothing read on the host in between
+    hs = [deferred(bufs[i]) for i in range(4)]
+    ctx.synchronize()
+    for i, h in enumerate(hs):
+        head, got = _fused(bufs[i], cap)
+        assert head == [len(want), 0] and np.array_equal(got, want)
+        assert np.array_equal(h.view(), want) and h.stats().fell_back == 0
+        h.close()
+    # a band list of 64 entries overflows (300 planted needles); the two scans behind it run on a table with leftovers
+    a = deferred(bufs[0], SPM_HIP_FILTER_BAND_CAP=64)
+    b = deferred(bufs[1])
+    c = deferred(bufs[2])
+    ctx.synchronize()
+    assert [bufs[i][0, 1].item() for i in range(3)] == [1, 1, 1]          # all three say "ask the host"
+    assert np.array_equal(c.view(), want)                                 # completed out of order: each repeats itself
+    assert np.array_equal(a.view(), want) and np.array_equal(b.view(), want)
+    for h in (a, b, c):
+        assert h.stats().fell_back == 0
+        h.close()
+    d = deferred(bufs[3])                                                 # the table is empty again
+    ctx.synchronize()
+    head, got = _fused(bufs[3], cap)
+    assert head == [len(want), 0] and np.array_equal(got, want)
+    d.close()
+    # an ordinary scan right behind a poisoned one that nobody has completed yet: heals itself (one repeated attempt)
+    a = deferred(bufs[0], SPM_HIP_FILTER_BAND_CAP=64)
+    plain = spm.scan(ctx, text, ps, engine=spm.ENGINE_FILTER)
+    assert np.array_equal(plain.view(), want) and plain.stats().fell_back == 0
+    assert np.array_equal(a.view(), want)
+    a.close()
+    plain.close()
