@@ -1062,6 +1062,7 @@ struct resolve_params
     // the host looked (deferred completion, SPM_SCAN_DEFER).  So the overflow is also recorded HERE, on the device, where it
     // sticks until the host has emptied the table: a scan that finds it set declares itself void.
     uint32_t *table_poison;
+    uint32_t debug_stage;   // diagnostics (SPM_HIP_RESOLVE_DEBUG): cut the kernel short after stage 1..4 to time the stages (wrong results)
 };
 
 // Band table slot: .x = key (kBandEmpty = all ones: free), .y = value kept so that a free slot is ALL ONES (one memset
@@ -1457,6 +1458,8 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
             live = seed_intact(R, t, val, (rng >> 16) & 0x1F, (rng & kRngWhole) ? R.key_len + ((rng >> 5) & 0x1F) : 0u, sb, se);
             rng |= kSeedChecked;
         }
+        if (R.debug_stage == 3)
+            live = false;
         through = live;
         if (live && R.pieces_check) {
             const uint32_t m = (uint32_t)R.m[pat], k = (uint32_t)R.k[pat];
@@ -1467,6 +1470,8 @@ __device__ __forceinline__ void check_pairs(const resolve_params &R, resolve_wav
             }
         }
     }
+    if (R.debug_stage == 4 && through)
+        live = false;
     // back into the queue: alive, not through
     {
         const bool back = live && !through;
@@ -1656,6 +1661,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                 }
             }
         }
+        if (R.debug_stage == 1)
+            cnt = 0;
         // ... then the (survivor, entry) pairs of the whole wave are dealt to its lanes, 64 at a time: pair i belongs to the
         // lane whose inclusive prefix sum of `cnt` is the first one above i
         uint32_t incl = cnt;
@@ -1706,6 +1713,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const resolve_params R)
                     }
                 }
             }
+            if (R.debug_stage == 2)
+                have = false;
             // queue the pairs that are left; 64 waiting pairs are resolved at once
             const uint64_t mm = __ballot(have);
             if (mm != 0) {

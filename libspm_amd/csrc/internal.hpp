@@ -101,6 +101,7 @@ struct scan_tuning
     int verify_runs = 1;
     int verify_runs_min_bands = 65536;
     int band_cap = 0;
+    int resolve_debug = 0;
     static scan_tuning from_env()
     {
         scan_tuning T;
@@ -133,6 +134,7 @@ struct scan_tuning
         T.verify_runs = env_int("SPM_HIP_VERIFY_RUNS", 1);
         T.verify_runs_min_bands = env_int("SPM_HIP_VERIFY_RUNS_MIN_BANDS", 65536);
         T.band_cap = env_int("SPM_HIP_FILTER_BAND_CAP", 0);
+        T.resolve_debug = env_int("SPM_HIP_RESOLVE_DEBUG", 0);
         return T;
     }
 };

@@ -532,6 +532,7 @@ int run_filter(const scan_args &A)
     R.overflow = H->d_count + 2;
     R.hit_cap = H->cap;
     R.table_poison = ctx->d_table_poison;
+    R.debug_stage = (uint32_t)A.tune.resolve_debug;
     R.table_mask = (uint32_t)(band_slots - 1);
     R.bands = d_bands;
     R.band_cap = band_cap;
