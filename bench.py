@@ -563,6 +563,7 @@ def run_scan(args, S, sdist, torch, dist, rank, world, dev, ctx, workload):
         text = ctx.generate(SEED_TEXT, lo - ovl, (hi - lo) + ovl)
         needles = [S.synth_pattern(SEED_TEXT, SEED_PAT, n_total, p, L, kmax)[0] for p in range(n_pat)]
     s_algo = S.ALGO_MYERS if algo == "myers" else S.ALGO_SHIFTOR
+    needles = np.stack(needles)     # reads of one length: one row each (the layout the C ABI takes; no per-needle Python work)
     # matcher construction (the reference: one constructor per needle, myers_matcher.hpp:40-43): host wall clock of the
     # call that builds every table of the set and uploads it -- not part of a step, reported beside it
     torch.cuda.synchronize()

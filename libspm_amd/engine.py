@@ -73,11 +73,20 @@ class Context:
 
     # ---- needles ----
     def patterns(self, algo: int, needles, k=0, sigma: int = 4) -> "PatternSet":
-        needles = [np.ascontiguousarray(p, dtype=np.uint8) for p in needles]
-        offs = np.zeros(len(needles) + 1, dtype=np.uint32)
-        if needles:
-            offs[1:] = np.cumsum([len(p) for p in needles])
-        cat = np.concatenate(needles) if needles and offs[-1] else np.zeros(1, np.uint8)
+        """needles: a sequence of rank arrays, or -- reads of one length -- a 2-D uint8 array, one needle per row (what the C ABI
+        takes anyway: ranks back to back + offsets; 100 000 rows cost a reshape instead of 100 000 Python objects)."""
+        if isinstance(needles, np.ndarray) and needles.ndim == 2:
+            mat = np.ascontiguousarray(needles, dtype=np.uint8)
+            n_needles = mat.shape[0]
+            offs = (np.arange(n_needles + 1, dtype=np.uint64) * mat.shape[1]).astype(np.uint32)
+            cat = mat.reshape(-1) if mat.size else np.zeros(1, np.uint8)
+            needles = mat          # (len() below)
+        else:
+            needles = [np.ascontiguousarray(p, dtype=np.uint8) for p in needles]
+            offs = np.zeros(len(needles) + 1, dtype=np.uint32)
+            if needles:
+                offs[1:] = np.cumsum([len(p) for p in needles])
+            cat = np.concatenate(needles) if needles and offs[-1] else np.zeros(1, np.uint8)
         if np.isscalar(k):
             ks = np.full(max(1, len(needles)), k, dtype=np.uint16)
         else:

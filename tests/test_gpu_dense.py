@@ -357,3 +357,18 @@ def test_deferred_completion_of_myers_scans_and_the_poisoned_band_table(spm, ctx
     assert np.array_equal(a.view(), want)
     a.close()
     plain.close()
+
+
+def test_needles_as_a_matrix_equal_needles_as_a_list(spm, ctx):
+    """Context.patterns takes reads of one length as a 2-D array (one row each): same set, same hits."""
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    T = rng.integers(0, 4, n, dtype=np.uint8)
+    rows = np.stack([T[a:a + 64] for a in rng.integers(0, n - 64, 300)])
+    text = ctx.upload(T)
+    a = ctx.patterns(spm.ALGO_MYERS, rows, k=2)
+    b = ctx.patterns(spm.ALGO_MYERS, [r.copy() for r in rows], k=2)
+    assert a.n == b.n == 300 and a.build_stats().keys == b.build_stats().keys
+    ha, hb = spm.scan(ctx, text, a).view(), spm.scan(ctx, text, b).view()
+    assert len(ha) >= 300 and np.array_equal(ha, hb)
+    assert ctx.patterns(spm.ALGO_SHIFTOR, np.zeros((0, 32), np.uint8)).n == 0
