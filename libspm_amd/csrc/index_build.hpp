@@ -1024,7 +1024,9 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
             pos_of[t] = std::vector<uint16_t>();
         }
     }
+    const double ms_first_fit = ms(t1);
     dense_share_bits(nv, T, A.dimers, cc, first, pos_flat);
+    const double ms_share = ms(t1) - ms_first_fit;
     X.seed_q.assign(nv.n, 0);
     X.seed_n.assign(nv.n, 0);
     X.seed_c.assign(nv.n, 1);
@@ -1086,8 +1088,9 @@ inline int build_dense_index(const needle_view &nv, const index_tuning &T, seed_
         for (uint32_t w : F.h_image)
             set += (uint64_t)__builtin_popcount(w);
         fprintf(stderr, "[spm_hip] dense index: %zu keys, anchors %u/16 (%u pattern(s)), %.1f %% of the presence bits set; anchors %.2f ms, "
-                        "layouts %.2f, bits + buckets %.2f, directory %.2f (%u threads)\n", n_keys, A.sixteenths(), A.n_pat,
-                100.0 * (double)set / (double)(1u << kDenseBloomBits), ms_anchors, ms_layout, ms_level1, ms(t3), nt);
+                        "layouts %.2f (first fit %.2f, shared bits %.2f), bits + buckets %.2f, directory %.2f (%u threads)\n", n_keys,
+                A.sixteenths(), A.n_pat, 100.0 * (double)set / (double)(1u << kDenseBloomBits), ms_anchors, ms_layout, ms_first_fit,
+                ms_share, ms_level1, ms(t3), nt);
     }
     F.ok = true;
     X.fidx.push_back(std::move(F));
