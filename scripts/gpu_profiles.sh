@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$(pwd); TAG=${TAG:-r03}; PART=${PART:-1}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 say() { echo "== $* ==" | tee -a $OUT/progress.log; }
 B="python3 $R/bench.py --no-cpu-baseline --brute-sample-mib 0 --packed-steps 0 --no-other-configs"
-steps_of() { case $1 in c4|reads100) echo "--steps 3 --warmup 2";; c3r) echo "--steps 5 --warmup 3";; *) echo "--steps 10 --warmup 3";; esac; }
+steps_of() { case $1 in c4|reads100) echo "--steps 5 --warmup 3";; c3r) echo "--steps 5 --warmup 3";; *) echo "--steps 10 --warmup 3";; esac; }
 if [ $PART = 1 ]; then
   say "default bench line (all configs)"
   timeout -k 10 600 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -5 $OUT/bench_default.err; exit 1; }
