@@ -74,6 +74,21 @@ struct nucleotide
     constexpr operator char() const noexcept { return to_char(); }
 };
 
+// Serialisation as the rank, the way the reference gives its symbols to cereal (seqan/alphabet.hpp:85-98,328-341: minimal
+// save / load functions found by ADL).  cereal is not a dependency of this header: the two names below are the ones
+// CEREAL_SAVE_MINIMAL_FUNCTION_NAME / CEREAL_LOAD_MINIMAL_FUNCTION_NAME expand to by default, so an archive that is present
+// picks them up; any type can stand in for `archive_t`.
+template <typename archive_t, std::size_t sigma, auto const & table>
+constexpr std::uint8_t save_minimal(archive_t const &, nucleotide<sigma, table> const & symbol) noexcept
+{
+    return symbol.to_rank();
+}
+template <typename archive_t, std::size_t sigma, auto const & table>
+constexpr void load_minimal(archive_t const &, nucleotide<sigma, table> & symbol, std::uint8_t const & rank) noexcept
+{
+    symbol.assign_rank(rank);
+}
+
 using dna4 = nucleotide<4, detail::dna4_table>;
 using dna5 = nucleotide<5, detail::dna5_table>;
 using dna15 = nucleotide<15, detail::dna15_table>;

@@ -278,6 +278,19 @@ static void batch_cases()
 
 static void alphabet_cases()
 {
+    { // serialisation as the rank (the minimal save / load pair cereal looks up by ADL: alphabet.hpp:85-98 in the reference)
+        struct archive {} const ar{};
+        spm::dna5 const n{'N'};
+        EXPECT_EQ(save_minimal(ar, n), std::uint8_t{3});
+        spm::dna5 back{};
+        load_minimal(ar, back, save_minimal(ar, n));
+        EXPECT_TRUE(back == n && back.to_char() == 'N');
+        spm::dna15 y{};
+        load_minimal(ar, y, save_minimal(ar, spm::dna15{'Y'}));
+        EXPECT_EQ(y.to_char(), 'Y');
+        static_assert(save_minimal(0, spm::dna4{'G'}) == 2);
+    }
+
     static_assert(sizeof(spm::dna4) == 1 && sizeof(spm::dna5) == 1 && sizeof(spm::dna15) == 1);
     static_assert(std::semiregular<spm::dna4> && std::totally_ordered<spm::dna4>);
     EXPECT_EQ(spm::alphabet_size_v<spm::dna4>, std::size_t{4});
