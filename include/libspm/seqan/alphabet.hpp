@@ -125,3 +125,26 @@ inline namespace literals
     }
 } // namespace literals
 } // namespace spm
+
+// The two SeqAn2 metafunctions the reference specialises for its symbols (seqan/alphabet.hpp:100-112), under the names its
+// call sites use: number of symbols and bits per symbol (dna4: 4 / 2, dna5: 5 / 3, dna15: 15 / 4).
+namespace seqan2
+{
+template <typename symbol_t>
+struct ValueSize;
+template <typename symbol_t>
+struct BitsPerValue;
+
+template <std::size_t sigma, auto const & table>
+struct ValueSize<spm::nucleotide<sigma, table>>
+{
+    using Type = std::size_t;
+    static constexpr Type VALUE = sigma;
+};
+template <std::size_t sigma, auto const & table>
+struct BitsPerValue<spm::nucleotide<sigma, table>>
+{
+    using Type = std::size_t;
+    static constexpr Type VALUE = sigma <= 2 ? 1 : sigma <= 4 ? 2 : sigma <= 8 ? 3 : sigma <= 16 ? 4 : 8;
+};
+} // namespace seqan2

@@ -290,6 +290,10 @@ static void alphabet_cases()
         EXPECT_EQ(y.to_char(), 'Y');
         static_assert(save_minimal(0, spm::dna4{'G'}) == 2);
     }
+    // seqan2::ValueSize / BitsPerValue of the symbols (alphabet.hpp:100-112 in the reference)
+    static_assert(seqan2::ValueSize<spm::dna4>::VALUE == 4 && seqan2::BitsPerValue<spm::dna4>::VALUE == 2);
+    static_assert(seqan2::ValueSize<spm::dna5>::VALUE == 5 && seqan2::BitsPerValue<spm::dna5>::VALUE == 3);
+    static_assert(seqan2::ValueSize<spm::dna15>::VALUE == 15 && seqan2::BitsPerValue<spm::dna15>::VALUE == 4);
 
     static_assert(sizeof(spm::dna4) == 1 && sizeof(spm::dna5) == 1 && sizeof(spm::dna15) == 1);
     static_assert(std::semiregular<spm::dna4> && std::totally_ordered<spm::dna4>);
