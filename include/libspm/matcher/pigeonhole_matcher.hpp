@@ -22,10 +22,19 @@ namespace seqan2
 {
 struct PigeonholeSeedOnlyPosition
 {
-    std::size_t index{};  // needle
-    std::size_t offset{}; // begin of the seed inside the needle
-    std::size_t count{};  // seed length
+    std::ptrdiff_t index{};  // needle          (signed, as in the reference: pigeonhole_matcher.hpp:39-42)
+    std::ptrdiff_t offset{}; // begin of the seed inside the needle
+    std::ptrdiff_t count{};  // seed length
     constexpr bool operator==(PigeonholeSeedOnlyPosition const &) const noexcept = default;
+
+    // "<needle, offset, count>", the format the reference's tests print on a mismatch (pigeonhole_matcher.hpp:48-53)
+    template <typename stream_t, typename me_t>
+        requires std::same_as<std::remove_cvref_t<me_t>, PigeonholeSeedOnlyPosition>
+    friend stream_t & operator<<(stream_t & stream, me_t && me)
+    {
+        stream << "<" << me.index << ", " << me.offset << ", " << me.count << ">";
+        return stream;
+    }
 };
 } // namespace seqan2
 
@@ -158,7 +167,8 @@ private:
         std::vector<spm_hit> order(rec, rec + cnt);
         std::stable_sort(order.begin(), order.end(), [](spm_hit const & a, spm_hit const & b) { return a.pos < b.pos; });
         for (spm_hit const & x : order) {
-            _position = {_seeds[x.pattern].index, _seeds[x.pattern].offset, _q};
+            _position = {static_cast<std::ptrdiff_t>(_seeds[x.pattern].index), static_cast<std::ptrdiff_t>(_seeds[x.pattern].offset),
+                         static_cast<std::ptrdiff_t>(_q)};
             std::size_t const pos = static_cast<std::size_t>(x.pos) - base;
             finder f{pos, pos + _q, n, 0};
             callback(f);

@@ -10,6 +10,7 @@
 // callback, copies).  No gtest in this image: a 20-line EXPECT harness, exit code = number of failures.
 #include <algorithm>
 #include <cstdio>
+#include <sstream>
 #include <utility>
 #include <vector>
 
@@ -201,6 +202,12 @@ static void prefix_cases()
 
 static void pigeonhole_cases()
 {
+    { // the position prints as the reference's does
+        std::ostringstream os;
+        os << seqan2::PigeonholeSeedOnlyPosition{1, 5, 5};
+        EXPECT_TRUE(os.str() == "<1, 5, 5>");
+    }
+
     using needle_position_t = seqan2::PigeonholeSeedOnlyPosition;
     sequence_t const needle2 = "TGACTAGCAC"_dna4;
     std::vector<sequence_t> const multi_needle{needle, needle2};
