@@ -48,6 +48,8 @@ public:
     using value_type = std::ranges::range_value_t<range_t>;
     using reference = std::ranges::range_reference_t<range_t>;
     using iterator = std::ranges::iterator_t<range_t>;
+    using const_reference = std::ranges::range_reference_t<std::remove_const_t<range_t> const>; // (container_adapter.hpp:32-34)
+    using const_iterator = std::ranges::iterator_t<std::remove_const_t<range_t> const>;
     using difference_type = std::ranges::range_difference_t<range_t>;
     using size_type = std::make_unsigned_t<difference_type>;
 

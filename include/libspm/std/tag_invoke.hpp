@@ -46,4 +46,21 @@ inline constexpr bool is_nothrow_tag_invocable_v = nothrow_tag_invocable<cpo_t, 
 
 template <typename cpo_t, typename... args_t>
 using tag_invoke_result_t = decltype(std::tag_invoke(std::declval<cpo_t>(), std::declval<args_t>()...));
+
+// the trait spellings of the same questions (tag_invoke.hpp:79-102 in the reference)
+template <typename cpo_t, typename... args_t>
+inline constexpr bool is_tag_invocable_v = tag_invocable<cpo_t, args_t...>;
+template <typename cpo_t, typename... args_t>
+using is_tag_invocable = std::bool_constant<is_tag_invocable_v<cpo_t, args_t...>>;
+template <typename cpo_t, typename... args_t>
+using is_nothrow_tag_invocable = std::bool_constant<is_nothrow_tag_invocable_v<cpo_t, args_t...>>;
+template <typename cpo_t, typename... args_t>
+struct tag_invoke_result // ::type exists iff the call is well-formed
+{};
+template <typename cpo_t, typename... args_t>
+    requires tag_invocable<cpo_t, args_t...>
+struct tag_invoke_result<cpo_t, args_t...>
+{
+    using type = tag_invoke_result_t<cpo_t, args_t...>;
+};
 } // namespace std

@@ -297,6 +297,10 @@ static void alphabet_cases()
         EXPECT_EQ(y.to_char(), 'Y');
         static_assert(save_minimal(0, spm::dna4{'G'}) == 2);
     }
+    // the trait spellings of tag_invoke (std/tag_invoke.hpp:79-102 in the reference)
+    static_assert(std::is_tag_invocable_v<std::tag_t<spm::window_size>, spm::myers_matcher<sequence_t> const &>);
+    static_assert(!std::is_tag_invocable<std::tag_t<spm::window_size>, int>::value);
+    static_assert(std::same_as<std::tag_invoke_result<std::tag_t<spm::window_size>, spm::myers_matcher<sequence_t> const &>::type, std::size_t>);
     // seqan2::ValueSize / BitsPerValue of the symbols (alphabet.hpp:100-112 in the reference)
     static_assert(seqan2::ValueSize<spm::dna4>::VALUE == 4 && seqan2::BitsPerValue<spm::dna4>::VALUE == 2);
     static_assert(seqan2::ValueSize<spm::dna5>::VALUE == 5 && seqan2::BitsPerValue<spm::dna5>::VALUE == 3);
