@@ -183,7 +183,7 @@ extern "C" int spm_hip_patterns_create(spm_ctx *ctx, int algo, const uint8_t *ra
             up.add(reinterpret_cast<void **>(&ps->d_ranks), ps->ranks.data(), ps->ranks.size(), 64);
             SPM_HIP_CHECK(ctx, upload(&ps->d_offsets, ps->offsets.data(), ps->offsets.size() * sizeof(uint32_t)));
             if (ps->sigma == 4) { // the same symbols 2 bits each, 16 per word, every needle from a word of its own
-                pack_needles(nv, pk, pk_off);
+                pack_needles(nv, pk, pk_off, tune.n_threads());
                 SPM_HIP_CHECK(ctx, upload(&ps->d_needle_pk, pk.data(), pk.size() * sizeof(uint32_t)));
                 SPM_HIP_CHECK(ctx, upload(&ps->d_pk_offsets, pk_off.data(), pk_off.size() * sizeof(uint32_t)));
             }
