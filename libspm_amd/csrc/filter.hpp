@@ -1830,7 +1830,7 @@ __device__ __forceinline__ uint32_t band_lookup(const verify_params &P, unsigned
 __global__ __launch_bounds__(256) void band_runs_kernel(const verify_params P, band_rec *bands, band_rec *heads,
                                                         unsigned long long *head_count)
 {
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot01[4], wave_tot23[4];
     __shared__ unsigned long long chunk_base;
     unsigned long long n = P.counters[P.band_counter];
     if (n > P.band_cap)
@@ -1876,30 +1876,65 @@ __global__ __launch_bounds__(256) void band_runs_kernel(const verify_params P, b
             c.val = (c.val & ~0x7FFu) | code;
             mine[j] = c;
         }
-        // where this thread's heads go: exclusive prefix over the workgroup, one reservation per chunk
-        uint32_t incl = cnt;
+        // where this thread's heads go: one reservation per chunk, and inside the chunk the heads are laid out BY RUN LENGTH
+        // (class = followers, 0..3): the verification takes 64 consecutive heads per wave and runs as long as its longest
+        // run -- 231 columns for four bands against 135 for one --, so waves of one class waste nothing.  Four 16-bit counters
+        // (<= 2048 heads per chunk) travel in two words through the prefix sums.
+        uint32_t c01 = 0, c23 = 0; // this thread's heads per class: classes 0, 1 in c01 (low, high half), 2, 3 in c23
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j)
+            if (head_mask & (1u << j)) {
+                const uint32_t cls = (mine[j].val >> kRunLenShift) & kRunLenMask;
+                const uint32_t one = 1u << (16 * (cls & 1u));
+                c01 += cls < 2 ? one : 0u;
+                c23 += cls < 2 ? 0u : one;
+            }
+        uint32_t i01 = c01, i23 = c23;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-            if (lane >= (uint32_t)o)
-                incl += up;
+            const uint32_t u01 = (uint32_t)__shfl_up((int)i01, o), u23 = (uint32_t)__shfl_up((int)i23, o);
+            if (lane >= (uint32_t)o) {
+                i01 += u01;
+                i23 += u23;
+            }
         }
-        if (lane == 63)
-            wave_tot[wave] = incl;
+        if (lane == 63) {
+            wave_tot01[wave] = i01;
+            wave_tot23[wave] = i23;
+        }
         __syncthreads();
-        uint32_t wave_off = 0, total = 0;
+        uint32_t off01 = 0, off23 = 0, tot01 = 0, tot23 = 0;
         for (uint32_t w = 0; w < 4; ++w) {
-            wave_off += w < wave ? wave_tot[w] : 0u;
-            total += wave_tot[w];
+            off01 += w < wave ? wave_tot01[w] : 0u;
+            off23 += w < wave ? wave_tot23[w] : 0u;
+            tot01 += wave_tot01[w];
+            tot23 += wave_tot23[w];
         }
+        const uint32_t tot[4] = {tot01 & 0xFFFFu, tot01 >> 16, tot23 & 0xFFFFu, tot23 >> 16};
+        const uint32_t total = tot[0] + tot[1] + tot[2] + tot[3];
         if (tid == 0)
             chunk_base = total ? atomicAdd(head_count, (unsigned long long)total) : 0ull;
         __syncthreads();
-        uint64_t pos = chunk_base + wave_off + incl - cnt;
+        // class c starts behind the classes before it; inside it: the waves before this one, then the lanes before this one
+        const uint32_t mine_before[4] = {(off01 & 0xFFFFu) + ((i01 - c01) & 0xFFFFu), (off01 >> 16) + ((i01 - c01) >> 16),
+                                         (off23 & 0xFFFFu) + ((i23 - c23) & 0xFFFFu), (off23 >> 16) + ((i23 - c23) >> 16)};
+        uint64_t pos[4];
+        pos[0] = chunk_base + mine_before[0];
+        pos[1] = chunk_base + tot[0] + mine_before[1];
+        pos[2] = chunk_base + tot[0] + tot[1] + mine_before[2];
+        pos[3] = chunk_base + tot[0] + tot[1] + tot[2] + mine_before[3];
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j)
-            if (head_mask & (1u << j))
-                heads[pos++] = mine[j]; // (<= the entries of the input list)
+            if (head_mask & (1u << j)) {
+                const uint32_t cls = (mine[j].val >> kRunLenShift) & kRunLenMask;
+                // (a select chain instead of pos[cls]: a dynamically indexed array would live in scratch memory)
+                const uint64_t at = cls == 0 ? pos[0] : cls == 1 ? pos[1] : cls == 2 ? pos[2] : pos[3];
+                heads[at] = mine[j]; // (<= the entries of the input list)
+                pos[0] += cls == 0 ? 1u : 0u;
+                pos[1] += cls == 1 ? 1u : 0u;
+                pos[2] += cls == 2 ? 1u : 0u;
+                pos[3] += cls == 3 ? 1u : 0u;
+            }
         __syncthreads();
     }
 }
