@@ -215,6 +215,8 @@ int run_filter(const scan_args &A)
     const bool skip_seen = exact_hits && !A.need_seen && A.tune.exact_skip_dedupe != 0;
     const_cast<scan_args &>(A).seen_skipped = skip_seen;
     const_cast<scan_args &>(A).exact_used = exact_hits;
+    if (!skip_seen)
+        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
     if (!exact_hits)
         ctx->band_dirty = true; // until the verification has consumed every band of this scan
 
@@ -544,10 +546,6 @@ int run_filter(const scan_args &A)
     // (a short survivor list: one survivor per lane, its latency is the kernel's; a long one: four per lane)
     const uint64_t per_wg = (surv_expect + 255) / 256 <= rmax ? 256 : (uint64_t)std::max(256, A.tune.resolve_surv_per_wg);
     const uint32_t rgrid = (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(ctx->n_cu / 2, (surv_expect + per_wg - 1) / per_wg));
-    // the dedupe set is emptied HERE, behind the streaming kernel (its first user is the resolve kernel of exact sets, then
-    // the verification): filled in front of it, its 64 MiB .. 1 GiB of dirty lines were written back while the text streamed
-    if (!skip_seen)
-        SPM_HIP_CHECK(ctx, hipMemsetAsync(d_seen, 0xFF, seen_bytes, ctx->stream));
     hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(256), 0, ctx->stream, R);
     SPM_HIP_CHECK(ctx, hipGetLastError());
 
